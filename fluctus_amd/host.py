@@ -1,0 +1,154 @@
+"""ctypes binding of libfluctus_host.so (C++ scene / BVH / env-map preparation)."""
+import ctypes as C
+import os
+import numpy as np
+from .wire import TRIANGLE, NODE, MATERIAL, TEXDESC
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libfluctus_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing -- run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(path)
+        _lib.fh_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("libfluctus_host: " + lib().fh_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class SceneData:
+    """Triangles/materials/textures in wire format + BVH arrays."""
+
+    def __init__(self):
+        self.tris = self.materials = self.texdesc = self.texdata = None
+        self.nodes = self.indices = None
+        self.world_radius = 1.0
+        self.type_bits = 0
+        self.bvh_metrics = None
+
+
+def _scene_to_data(h):
+    L = lib()
+    nt, nm, nx, tb, bits = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+    _chk(L.fh_scene_counts(h, C.byref(nt), C.byref(nm), C.byref(nx), C.byref(tb), C.byref(bits)))
+    d = SceneData()
+    d.tris = np.zeros(nt.value, TRIANGLE)
+    d.materials = np.zeros(nm.value, MATERIAL)
+    d.texdesc = np.zeros(nx.value, TEXDESC)
+    d.texdata = np.zeros(tb.value, np.uint8)
+    _chk(L.fh_scene_get(h, _p(d.tris), _p(d.materials), _p(d.texdesc), _p(d.texdata)))
+    d.type_bits = bits.value
+    return d
+
+
+def load_scene(path):
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_scene_create(C.byref(h)))
+    try:
+        _chk(L.fh_scene_load(h, path.encode()))
+        return _scene_to_data(h)
+    finally:
+        L.fh_scene_destroy(h)
+
+
+def generate_scene(kind, target_tris, seed):
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_scene_create(C.byref(h)))
+    try:
+        _chk(L.fh_scene_generate(h, kind.encode(), C.c_uint32(target_tris), C.c_uint32(seed)))
+        return _scene_to_data(h)
+    finally:
+        L.fh_scene_destroy(h)
+
+
+BVH_MODES = {"sbvh": 0, "sah": 1, "binned": 2}
+
+
+def build_bvh(d, mode="sbvh"):
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_bvh_build(_p(d.tris), C.c_uint64(d.tris.size), BVH_MODES[mode], C.byref(h)))
+    try:
+        nn, ni = C.c_uint64(), C.c_uint64()
+        met = (C.c_uint32 * 4)()
+        _chk(L.fh_bvh_counts(h, C.byref(nn), C.byref(ni), met))
+        d.nodes = np.zeros(nn.value, NODE)
+        d.indices = np.zeros(ni.value, np.uint32)
+        wr = C.c_float()
+        _chk(L.fh_bvh_get(h, _p(d.nodes), _p(d.indices), C.byref(wr)))
+        d.world_radius = wr.value
+        d.bvh_metrics = dict(depth=met[0], splits=met[1], duplicates=met[2], spatial_splits=met[3])
+    finally:
+        L.fh_bvh_destroy(h)
+    return d
+
+
+class EnvMap:
+    def __init__(self, w, h, rgb, prob, alias, pdf):
+        self.w, self.h, self.rgb, self.prob, self.alias, self.pdf = w, h, rgb, prob, alias, pdf
+
+
+def _env_to_py(h):
+    L = lib()
+    w, hh = C.c_int(), C.c_int()
+    L.fh_envmap_dims(h, C.byref(w), C.byref(hh))
+    n = w.value * hh.value
+    rgb = np.zeros(n * 3, np.float32)
+    prob = np.zeros(n, np.float32)
+    alias = np.zeros(n, np.int32)
+    pdf = np.zeros(n, np.float32)
+    _chk(L.fh_envmap_get(h, _p(rgb), _p(prob), _p(alias), _p(pdf)))
+    return EnvMap(w.value, hh.value, rgb, prob, alias, pdf)
+
+
+def load_envmap(path):
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_envmap_load(path.encode(), C.byref(h)))
+    try:
+        return _env_to_py(h)
+    finally:
+        L.fh_envmap_destroy(h)
+
+
+def envmap_from_rgb(w, h, rgb):
+    L = lib()
+    hd = C.c_void_p()
+    rgb = np.ascontiguousarray(rgb, np.float32).reshape(-1)
+    _chk(L.fh_envmap_from_memory(w, h, _p(rgb), C.byref(hd)))
+    try:
+        return _env_to_py(hd)
+    finally:
+        L.fh_envmap_destroy(hd)
+
+
+def synthetic_sky(w=512, h=256, seed=7):
+    """Deterministic HDR sky (gradient + a few bright lobes): the env map that travels to the GPU
+    box, where /root/reference (assets/env_maps/night.hdr) does not exist."""
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    uu, vv = np.meshgrid(u, v)
+    up = np.clip(1.0 - 2.0 * vv, 0.0, 1.0)
+    img = np.stack([0.25 + 0.35 * up, 0.35 + 0.45 * up, 0.55 + 0.75 * up], -1).astype(np.float32)
+    img[vv > 0.5] *= 0.25
+    rng = np.random.RandomState(seed)
+    for _ in range(4):
+        cu, cv, s, a = rng.uniform(0, 1), rng.uniform(0.1, 0.4), rng.uniform(0.01, 0.04), rng.uniform(20, 200)
+        du = np.minimum(np.abs(uu - cu), 1.0 - np.abs(uu - cu))
+        img += (a * np.exp(-((du ** 2) + (vv - cv) ** 2) / (2 * s * s)))[..., None].astype(np.float32) * \
+            np.array([1.0, 0.9, 0.7], np.float32)
+    return envmap_from_rgb(w, h, img.astype(np.float32))

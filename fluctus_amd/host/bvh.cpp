@@ -1,0 +1,388 @@
+// bvh.cpp -- see bvh.hpp.  Own implementation; decision rules follow the cited reference lines so
+// that the SBVH of a given mesh is the same tree the reference's builder produces.
+#include "bvh.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace fluctus {
+
+namespace {
+
+struct Ref { uint32_t ind; Box box; };
+
+Box triBox(const flx_triangle &t)
+{
+    Box b;
+    b.expand(&t.v0.p.x); b.expand(&t.v1.p.x); b.expand(&t.v2.p.x);
+    return b;
+}
+
+// sort key = box.min[d] + box.max[d], ties by triangle index (reference: src/bvh.cpp:258-272)
+void sortRefs(std::vector<Ref> &refs, size_t s, size_t e /*inclusive*/, int dim)
+{
+    std::sort(refs.begin() + s, refs.begin() + e + 1, [dim](const Ref &a, const Ref &b) {
+        float ca = a.box.mn[dim] + a.box.mx[dim], cb = b.box.mn[dim] + b.box.mx[dim];
+        return ca < cb || (ca == cb && a.ind < b.ind);
+    });
+}
+
+struct Split { int i = -1; float pos = 0; int dim = -1; float cost = FLT_MAX; Box left, right; };
+
+struct TreeNode { Box box; int left = -1, right = -1; uint32_t leafStart = 0, leafCount = 0; };
+
+flx_node makeNode(const Box &b, int parent)
+{
+    flx_node n; std::memset(&n, 0, sizeof(n));
+    n.bmin = flx_vec3{b.mn[0], b.mn[1], b.mn[2], 0}; n.bmax = flx_vec3{b.mx[0], b.mx[1], b.mx[2], 0};
+    n.parent = parent;
+    return n;
+}
+
+// ----------------------------------------------------------------------------------- SBVH
+struct SbvhBuilder {
+    enum { MaxLeaf = 8, MinLeaf = 1, MaxDepth = 64, MaxSpatialDepth = 48, Bins = 128 };   // src/sbvh.hpp:36-43
+    const std::vector<flx_triangle> &tris;
+    std::vector<Ref> refs;                // stack: a node owns the LAST spec.refs entries
+    std::vector<Box> rightBoxes;
+    std::vector<TreeNode> tree;
+    std::vector<uint32_t> leafInd;        // leaf contents, leaves appended in creation order
+    float minOverlap = 0;
+    uint32_t depthMax = 0, splits = 0, duplicates = 0, spatialSplits = 0;
+    struct Bin { Box bounds; int enter = 0, exit = 0; };
+    std::vector<Bin> bins;                // 3 * Bins
+
+    struct Spec { int refs = 0; Box box; };
+
+    explicit SbvhBuilder(const std::vector<flx_triangle> &t) : tris(t), bins(3 * Bins) {}
+
+    int leaf(const Spec &s)
+    {
+        TreeNode n; n.box = s.box; n.leafStart = (uint32_t)leafInd.size(); n.leafCount = (uint32_t)s.refs;
+        size_t first = refs.size() - s.refs;
+        for (int i = 0; i < s.refs; i++) leafInd.push_back(refs[first + i].ind);   // forward order (see bvh.hpp note)
+        refs.resize(first);
+        tree.push_back(n);
+        return (int)tree.size() - 1;
+    }
+
+    // full sweep on 3 axes (reference: src/sbvh.cpp:159-223)
+    Split sahSplit(const Spec &s, float nodeSAH)
+    {
+        Split best; float bestTie = FLT_MAX;
+        size_t start = refs.size() - s.refs, end = refs.size() - 1;
+        for (int dim = 0; dim < 3; dim++) {
+            sortRefs(refs, start, end, dim);
+            Box rb;
+            for (int i = s.refs - 1; i > 0; i--) { rb.expand(refs[start + i].box); rightBoxes[i - 1] = rb; }
+            Box lb;
+            for (int i = 1; i < s.refs; i++) {
+                lb.expand(refs[start + i - 1].box);
+                float cl = lb.area() * (float)i;
+                float cr = rightBoxes[i - 1].area() * (float)(s.refs - i);
+                float cost = nodeSAH + cl + cr;
+                float fi = (float)i, fr = (float)(s.refs - i);
+                float tie = fi * fi + fr * fr;
+                if (cost < best.cost || (cost == best.cost && tie < bestTie)) {
+                    best.cost = cost; best.i = i; best.left = lb; best.right = rightBoxes[i - 1]; best.dim = dim; bestTie = tie;
+                }
+            }
+        }
+        return best;
+    }
+
+    static float lerpf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+    // reference: src/sbvh.cpp:410-449
+    void splitReference(Ref &L, Ref &R, const Ref &ref, int dim, float coord) const
+    {
+        L.ind = R.ind = ref.ind; L.box = Box(); R.box = Box();
+        const flx_triangle &t = tris[ref.ind];
+        const float *v[3] = {&t.v0.p.x, &t.v1.p.x, &t.v2.p.x};
+        static const int prev[3] = {2, 0, 1};
+        for (int i = 0; i < 3; i++) {
+            const float *p2 = v[i], *p1 = v[prev[i]];
+            float a = p1[dim], b = p2[dim];
+            if (a <= coord) L.box.expand(p1);
+            if (a >= coord) R.box.expand(p1);
+            if ((a < coord && b > coord) || (a > coord && b < coord)) {
+                float tt = std::max(0.0f, std::min(1.0f, (coord - a) / (b - a)));
+                float q[3] = {lerpf(p1[0], p2[0], tt), lerpf(p1[1], p2[1], tt), lerpf(p1[2], p2[2], tt)};
+                L.box.expand(q); R.box.expand(q);
+            }
+        }
+        L.box.mx[dim] = coord; R.box.mn[dim] = coord;
+        L.box.intersect(ref.box); R.box.intersect(ref.box);
+    }
+
+    static int toBin(float v) { if (!(v == v) || v < -2147483000.0f) return 0; if (v > 2147483000.0f) return Bins - 1; int i = (int)v; return i < 0 ? 0 : (i > Bins - 1 ? Bins - 1 : i); }
+
+    // chopped binning, 128 bins per axis (reference: src/sbvh.cpp:243-324)
+    Split binSplit(const Spec &s, float nodeSAH)
+    {
+        float origin[3], binSize[3], inv[3];
+        for (int k = 0; k < 3; k++) { origin[k] = s.box.mn[k]; binSize[k] = (s.box.mx[k] - origin[k]) * (1.0f / (float)Bins); inv[k] = 1.0f / binSize[k]; }
+        for (auto &b : bins) { b.bounds = Box(); b.enter = b.exit = 0; }
+        for (size_t r = refs.size() - s.refs; r < refs.size(); r++) {
+            const Ref &ref = refs[r];
+            for (int dim = 0; dim < 3; dim++) {
+                int first = toBin((ref.box.mn[dim] - origin[dim]) * inv[dim]);
+                int last = toBin((ref.box.mx[dim] - origin[dim]) * inv[dim]);
+                if (last < first) last = first;
+                Ref cur = ref;
+                for (int i = first; i < last; i++) {
+                    Ref l, rr;
+                    float coord = origin[dim] + binSize[dim] * (float)(i + 1);
+                    splitReference(l, rr, cur, dim, coord);
+                    bins[dim * Bins + i].bounds.expand(l.box);
+                    cur = rr;
+                }
+                bins[dim * Bins + last].bounds.expand(cur.box);
+                bins[dim * Bins + first].enter++;
+                bins[dim * Bins + last].exit++;
+            }
+        }
+        Split sp;
+        for (int dim = 0; dim < 3; dim++) {
+            Box rb;
+            for (int i = Bins - 1; i > 0; i--) { rb.expand(bins[dim * Bins + i].bounds); rightBoxes[i - 1] = rb; }
+            Box lb; int ln = 0, rn = s.refs;
+            for (int i = 1; i < Bins; i++) {
+                lb.expand(bins[dim * Bins + i - 1].bounds);
+                ln += bins[dim * Bins + i - 1].enter;
+                rn -= bins[dim * Bins + i - 1].exit;
+                float sah = nodeSAH + lb.area() * (float)ln + rightBoxes[i - 1].area() * (float)rn;
+                if (sah < sp.cost) { sp.cost = sah; sp.dim = dim; sp.pos = origin[dim] + binSize[dim] * (float)i; }
+            }
+        }
+        return sp;
+    }
+
+    // reference: src/sbvh.cpp:225-241
+    void partitionObject(Spec &L, Spec &R, const Spec &s, const Split &sp)
+    {
+        sortRefs(refs, refs.size() - s.refs, refs.size() - 1, sp.dim);
+        L.refs = sp.i; L.box = sp.left; R.refs = s.refs - sp.i; R.box = sp.right;
+    }
+
+    // reference: src/sbvh.cpp:328-407
+    void partitionSpatial(Spec &L, Spec &R, const Spec &s, const Split &sp)
+    {
+        int leftStart = (int)refs.size() - s.refs, leftEnd = leftStart, rightStart = (int)refs.size();
+        L.box = Box(); R.box = Box();
+        for (int i = leftEnd; i < rightStart; i++) {
+            if (refs[i].box.mx[sp.dim] <= sp.pos) { L.box.expand(refs[i].box); std::swap(refs[i], refs[leftEnd++]); }
+            else if (refs[i].box.mn[sp.dim] >= sp.pos) { R.box.expand(refs[i].box); std::swap(refs[i--], refs[--rightStart]); }
+        }
+        while (leftEnd < rightStart) {
+            Ref lref, rref;
+            splitReference(lref, rref, refs[leftEnd], sp.dim, sp.pos);
+            Box lub = L.box, rub = R.box, ldb = L.box, rdb = R.box;
+            lub.expand(refs[leftEnd].box); rub.expand(refs[leftEnd].box);
+            ldb.expand(lref.box); rdb.expand(rref.box);
+            float lac = (float)(leftEnd - leftStart), rac = (float)((int)refs.size() - rightStart);
+            float lbc = (float)(leftEnd - leftStart + 1), rbc = (float)((int)refs.size() - rightStart + 1);
+            float unsplitLeft = lub.area() * lbc + R.box.area() * rac;
+            float unsplitRight = L.box.area() * lac + rub.area() * rbc;
+            float dup = ldb.area() * lbc + rdb.area() * rbc;
+            float mn = std::min(unsplitLeft, std::min(unsplitRight, dup));
+            if (mn == unsplitLeft) { L.box = lub; leftEnd++; }
+            else if (mn == unsplitRight) { R.box = rub; std::swap(refs[leftEnd], refs[--rightStart]); }
+            else { L.box = ldb; R.box = rdb; refs[leftEnd++] = lref; refs.push_back(rref); }
+        }
+        L.refs = leftEnd - leftStart; R.refs = (int)refs.size() - rightStart;
+    }
+
+    // reference: src/sbvh.cpp:105-157
+    int build(Spec &s, int depth)
+    {
+        depthMax = std::max(depthMax, (uint32_t)depth);
+        if (s.refs <= MinLeaf || depth >= MaxDepth) return leaf(s);
+        float parentArea = s.box.area();
+        float nodeSAH = parentArea * 2 * 1;
+        Split obj = sahSplit(s, nodeSAH);
+        Split spatial;
+        if (depth < MaxSpatialDepth) {
+            Box ov = obj.left; ov.intersect(obj.right);
+            if (ov.area() >= minOverlap) spatial = binSplit(s, nodeSAH);
+        }
+        float parentCost = parentArea * (float)s.refs;
+        float minCost = std::min(obj.cost, std::min(spatial.cost, parentCost));
+        if (minCost == parentCost && s.refs <= MaxLeaf) return leaf(s);
+        Spec L, R;
+        if (minCost == spatial.cost) { partitionSpatial(L, R, s, spatial); if (L.refs && R.refs) spatialSplits++; }
+        if (!L.refs || !R.refs) partitionObject(L, R, s, obj);
+        splits++;
+        duplicates += (uint32_t)(L.refs + R.refs - s.refs);
+        int rn = build(R, depth + 1);       // right first: duplicates live at the end of the ref stack
+        int ln = build(L, depth + 1);
+        TreeNode n; n.box = s.box; n.left = ln; n.right = rn;
+        tree.push_back(n);
+        return (int)tree.size() - 1;
+    }
+
+    // DFS, left child = next slot (reference: src/sbvh.cpp:52-73)
+    void emit(int t, int parent, std::vector<flx_node> &nodes, std::vector<uint32_t> &indices)
+    {
+        uint32_t id = (uint32_t)nodes.size();
+        nodes.push_back(makeNode(tree[t].box, parent));
+        if (tree[t].left < 0) {
+            if (tree[t].leafCount > 255) throw std::runtime_error("leaf too large for u8");
+            nodes[id].iStartOrRight = (uint32_t)indices.size();
+            nodes[id].nPrims = (uint8_t)tree[t].leafCount;
+            for (uint32_t i = 0; i < tree[t].leafCount; i++) indices.push_back(leafInd[tree[t].leafStart + i]);
+        } else {
+            emit(tree[t].left, (int)id, nodes, indices);
+            nodes[id].iStartOrRight = (uint32_t)nodes.size();
+            emit(tree[t].right, (int)id, nodes, indices);
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------- SAH / binned
+struct ObjBuilder {
+    enum { MaxLeaf = 8 };
+    std::vector<Ref> refs;
+    std::vector<Box> rightBoxes;
+    std::vector<flx_node> &nodes;
+    uint32_t depthMax = 0, splits = 0;
+    bool binned;
+    ObjBuilder(std::vector<flx_node> &n, bool b) : nodes(n), binned(b) {}
+
+    static Box boundsOf(const std::vector<Ref> &r, size_t s, size_t e) { Box b; for (size_t i = s; i <= e; i++) b.expand(r[i].box); return b; }
+
+    // reference: src/bvh.cpp:333-407 (areas normalised by the parent area, cost 2*cb + ...)
+    size_t sweepSplit(size_t s, size_t e, const Box &box)
+    {
+        float parentArea = box.area();
+        size_t n = e - s + 1; float bestCost = FLT_MAX; size_t bestI = s; int bestDim = 2;
+        for (int dim = 0; dim < 3; dim++) {
+            sortRefs(refs, s, e, dim);
+            Box rb; for (size_t i = 0; i < n; i++) { rb.expand(refs[e - i].box); rightBoxes[i] = rb; }
+            Box lb; uint32_t lc = 0;
+            for (size_t i = s; i < e; i++) {
+                lb.expand(refs[i].box); lc++;
+                const Box &r = rightBoxes[e - i - 1];
+                float lcost = (float)lc * lb.area() / parentArea, rcost = (float)(n - lc) * r.area() / parentArea;
+                float cost = 2.0f + (lcost + rcost);
+                if (cost < bestCost) { bestCost = cost; bestI = i; bestDim = dim; }
+            }
+        }
+        if (bestDim != 2) sortRefs(refs, s, e, bestDim);
+        if (bestI == s) bestI++; else if (bestI == e) bestI--;   // reference: src/bvh.cpp:394-404
+        return bestI;
+    }
+
+    size_t binnedSplit(size_t s, size_t e, const Box &)
+    {
+        const int NB = 32;
+        Box cb; for (size_t i = s; i <= e; i++) { float c[3]; for (int k = 0; k < 3; k++) c[k] = 0.5f * (refs[i].box.mn[k] + refs[i].box.mx[k]); cb.expand(c); }
+        float bestCost = FLT_MAX; int bestDim = -1, bestBin = -1;
+        for (int dim = 0; dim < 3; dim++) {
+            float ext = cb.mx[dim] - cb.mn[dim]; if (!(ext > 0)) continue;
+            Box bb[NB]; uint32_t cnt[NB] = {0}; float sc = (float)NB / ext;
+            for (size_t i = s; i <= e; i++) { float c = 0.5f * (refs[i].box.mn[dim] + refs[i].box.mx[dim]); int b = std::min(NB - 1, std::max(0, (int)((c - cb.mn[dim]) * sc))); bb[b].expand(refs[i].box); cnt[b]++; }
+            Box rb[NB]; Box acc; for (int b = NB - 1; b > 0; b--) { acc.expand(bb[b]); rb[b] = acc; }
+            Box lb; uint32_t lc = 0, tot = (uint32_t)(e - s + 1);
+            for (int b = 0; b < NB - 1; b++) { lb.expand(bb[b]); lc += cnt[b]; if (!lc || lc == tot) continue; float cost = lb.area() * lc + rb[b + 1].area() * (tot - lc); if (cost < bestCost) { bestCost = cost; bestDim = dim; bestBin = b; } }
+        }
+        if (bestDim < 0) { size_t mid = (s + e) / 2; std::nth_element(refs.begin() + s, refs.begin() + mid, refs.begin() + e + 1, [](const Ref &a, const Ref &b) { return a.ind < b.ind; }); return mid; }
+        float ext = cb.mx[bestDim] - cb.mn[bestDim], sc = (float)NB / ext; int d = bestDim, bsel = bestBin; float mn = cb.mn[d];
+        auto it = std::stable_partition(refs.begin() + s, refs.begin() + e + 1, [=](const Ref &r) { float c = 0.5f * (r.box.mn[d] + r.box.mx[d]); int b = std::min(NB - 1, std::max(0, (int)((c - mn) * sc))); return b <= bsel; });
+        size_t split = (size_t)(it - refs.begin());
+        if (split <= s || split > e) split = (s + e + 1) / 2;
+        return split - 1;   // last index of the left part
+    }
+
+    // reference: src/bvh.cpp:221-256 (left child pushed right after the parent)
+    void build(size_t s, size_t e, int parent, uint32_t depth)
+    {
+        uint32_t id = (uint32_t)nodes.size();
+        Box box = boundsOf(refs, s, e);
+        nodes.push_back(makeNode(box, parent));
+        depthMax = std::max(depthMax, depth);
+        size_t n = e - s + 1;
+        if (n <= MaxLeaf || depth >= 62) {
+            if (n > 255) throw std::runtime_error("leaf too large for u8");
+            nodes[id].iStartOrRight = (uint32_t)s; nodes[id].nPrims = (uint8_t)n;
+            return;
+        }
+        size_t i = binned ? binnedSplit(s, e, box) : sweepSplit(s, e, box);
+        splits++;
+        build(s, i, (int)id, depth + 1);
+        nodes[id].iStartOrRight = (uint32_t)nodes.size();
+        build(i + 1, e, (int)id, depth + 1);
+    }
+};
+
+} // namespace
+
+void BVH::build(const std::vector<flx_triangle> *tris, Mode mode)
+{
+    m_tris = tris;
+    m_nodes.clear(); m_indices.clear();
+    const size_t n = tris->size();
+    if (n == 0) throw std::runtime_error("BVH: empty mesh");
+    if (mode == Mode::SBVH) {
+        SbvhBuilder b(*tris);
+        SbvhBuilder::Spec root; root.refs = (int)n;
+        b.refs.resize(n);
+        for (size_t i = 0; i < n; i++) { b.refs[i].ind = (uint32_t)i; b.refs[i].box = triBox((*tris)[i]); root.box.expand(b.refs[i].box); }
+        b.rightBoxes.resize(std::max(n, (size_t)SbvhBuilder::Bins));
+        b.minOverlap = root.box.area() * 1e-5f;           // splitAlpha (src/sbvh.hpp:70)
+        int r = b.build(root, 0);
+        b.emit(r, -1, m_nodes, m_indices);
+        metrics.depth = b.depthMax; metrics.splits = b.splits; metrics.duplicates = b.duplicates; metrics.spatialSplits = b.spatialSplits;
+    } else {
+        ObjBuilder b(m_nodes, mode == Mode::Binned);
+        b.refs.resize(n); b.rightBoxes.resize(n);
+        for (size_t i = 0; i < n; i++) { b.refs[i].ind = (uint32_t)i; b.refs[i].box = triBox((*tris)[i]); }
+        b.build(0, n - 1, -1, 0);
+        m_indices.resize(n);
+        for (size_t i = 0; i < n; i++) m_indices[i] = b.refs[i].ind;
+        metrics.depth = b.depthMax; metrics.splits = b.splits;
+    }
+}
+
+void BVH::getSceneBounds(float mn[3], float mx[3]) const
+{
+    if (m_nodes.empty()) throw std::runtime_error("Cannot get scene bounds from uninitialized BVH");
+    mn[0] = m_nodes[0].bmin.x; mn[1] = m_nodes[0].bmin.y; mn[2] = m_nodes[0].bmin.z;
+    mx[0] = m_nodes[0].bmax.x; mx[1] = m_nodes[0].bmax.y; mx[2] = m_nodes[0].bmax.z;
+}
+
+float BVH::worldRadius() const
+{
+    float mn[3], mx[3]; getSceneBounds(mn, mx);
+    float d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    return std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) * 0.5f;
+}
+
+void BVH::exportTo(const std::string &filename) const
+{
+    std::ofstream out(filename, std::ios::binary);
+    if (!out) return;
+    const char magic[8] = {'F', 'L', 'X', 'B', 'V', 'H', '1', 0};
+    uint64_t ni = m_indices.size(), nn = m_nodes.size();
+    out.write(magic, 8); out.write((const char *)&ni, 8); out.write((const char *)&nn, 8);
+    out.write((const char *)m_indices.data(), ni * sizeof(uint32_t));
+    out.write((const char *)m_nodes.data(), nn * sizeof(flx_node));
+}
+
+bool BVH::importFrom(const std::string &filename)
+{
+    std::ifstream in(filename, std::ios::binary);
+    if (!in) return false;
+    char magic[8]; uint64_t ni = 0, nn = 0;
+    in.read(magic, 8); in.read((char *)&ni, 8); in.read((char *)&nn, 8);
+    if (!in || std::memcmp(magic, "FLXBVH1", 7) != 0) return false;
+    m_indices.resize(ni); m_nodes.resize(nn);
+    in.read((char *)m_indices.data(), ni * sizeof(uint32_t));
+    in.read((char *)m_nodes.data(), nn * sizeof(flx_node));
+    return (bool)in;
+}
+
+} // namespace fluctus

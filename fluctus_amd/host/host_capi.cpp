@@ -1,0 +1,113 @@
+// host_capi.cpp -- C entry points of libfluctus_host.so (scene / BVH / env-map preparation).
+// Pure CPU, no device code.  Consumed by the Python harness (tests, bench.py) through ctypes and
+// by the C++ Tracer.  Every function returns 0 on success, non-zero on error (message via
+// fh_last_error()), never throws across the boundary.
+#include "scene.hpp"
+#include "bvh.hpp"
+#include "envmap.hpp"
+#include <cstring>
+#include <string>
+#include <exception>
+#include <stdexcept>
+
+using namespace fluctus;
+
+static thread_local std::string g_err;
+#define FH_TRY try {
+#define FH_CATCH } catch (const std::exception &e) { g_err = e.what(); return 1; } catch (...) { g_err = "unknown error"; return 1; } return 0;
+
+extern "C" {
+
+const char *fh_last_error() { return g_err.c_str(); }
+
+// ---- Scene
+int fh_scene_create(void **out) { FH_TRY *out = new Scene(); FH_CATCH }
+int fh_scene_destroy(void *s) { delete (Scene *)s; return 0; }
+int fh_scene_load(void *s, const char *path) { FH_TRY ((Scene *)s)->loadModel(path); FH_CATCH }
+int fh_scene_generate(void *s, const char *kind, uint32_t targetTris, uint32_t seed) { FH_TRY ((Scene *)s)->generate(kind, targetTris, seed); FH_CATCH }
+int fh_scene_counts(void *s, uint64_t *ntris, uint64_t *nmats, uint64_t *ntex, uint64_t *texbytes, uint32_t *typeBits)
+{
+    FH_TRY
+    Scene *sc = (Scene *)s;
+    *ntris = sc->getTriangles().size(); *nmats = sc->getMaterials().size(); *ntex = sc->getTextures().size();
+    uint64_t b = 0; for (auto &t : sc->getTextures()) b += (uint64_t)t.width * t.height * 4;
+    *texbytes = b; *typeBits = sc->getMaterialTypes();
+    FH_CATCH
+}
+int fh_scene_get(void *s, void *tris, void *mats, void *texdesc, uint8_t *texdata)
+{
+    FH_TRY
+    Scene *sc = (Scene *)s;
+    if (tris) memcpy(tris, sc->getTriangles().data(), sc->getTriangles().size() * sizeof(flx_triangle));
+    if (mats) memcpy(mats, sc->getMaterials().data(), sc->getMaterials().size() * sizeof(flx_material));
+    std::vector<flx_texdesc> d; std::vector<uint8_t> blob;
+    sc->packTextures(d, blob);
+    if (texdesc && !d.empty()) memcpy(texdesc, d.data(), d.size() * sizeof(flx_texdesc));
+    if (texdata && !blob.empty()) memcpy(texdata, blob.data(), blob.size());
+    FH_CATCH
+}
+int fh_scene_add_material(void *s, const void *mat80, int *idx) { FH_TRY *idx = ((Scene *)s)->addMaterial(*(const flx_material *)mat80); FH_CATCH }
+int fh_scene_set_tri_material(void *s, uint64_t first, uint64_t count, int matId)
+{
+    FH_TRY
+    auto &t = ((Scene *)s)->getTriangles();
+    for (uint64_t i = first; i < first + count && i < t.size(); i++) t[i].matId = matId;
+    FH_CATCH
+}
+
+// ---- BVH   mode: 0 = SBVH, 1 = SAH sweep, 2 = binned
+int fh_bvh_build(const void *tris, uint64_t ntris, int mode, void **out)
+{
+    FH_TRY
+    std::vector<flx_triangle> *copy = new std::vector<flx_triangle>((const flx_triangle *)tris, (const flx_triangle *)tris + ntris);
+    BVH *b = new BVH();
+    try { b->build(copy, mode == 0 ? BVH::Mode::SBVH : mode == 1 ? BVH::Mode::SAH : BVH::Mode::Binned); }
+    catch (...) { delete copy; delete b; throw; }
+    delete copy;
+    *out = b;
+    FH_CATCH
+}
+int fh_bvh_destroy(void *b) { delete (BVH *)b; return 0; }
+int fh_bvh_counts(void *b, uint64_t *nnodes, uint64_t *nidx, uint32_t *metrics4)
+{
+    FH_TRY
+    BVH *v = (BVH *)b; *nnodes = v->m_nodes.size(); *nidx = v->m_indices.size();
+    if (metrics4) { metrics4[0] = v->metrics.depth; metrics4[1] = v->metrics.splits; metrics4[2] = v->metrics.duplicates; metrics4[3] = v->metrics.spatialSplits; }
+    FH_CATCH
+}
+int fh_bvh_get(void *b, void *nodes, uint32_t *indices, float *worldRadius)
+{
+    FH_TRY
+    BVH *v = (BVH *)b;
+    if (nodes) memcpy(nodes, v->m_nodes.data(), v->m_nodes.size() * sizeof(flx_node));
+    if (indices) memcpy(indices, v->m_indices.data(), v->m_indices.size() * 4);
+    if (worldRadius) *worldRadius = v->worldRadius();
+    FH_CATCH
+}
+int fh_bvh_export(void *b, const char *path) { FH_TRY ((BVH *)b)->exportTo(path); FH_CATCH }
+int fh_bvh_import(const char *path, void **out)
+{
+    FH_TRY
+    BVH *b = new BVH();
+    if (!b->importFrom(path)) { delete b; throw std::runtime_error(std::string("cannot import BVH from ") + path); }
+    *out = b;
+    FH_CATCH
+}
+
+// ---- Environment map
+int fh_envmap_load(const char *path, void **out) { FH_TRY *out = new EnvironmentMap(path); FH_CATCH }
+int fh_envmap_from_memory(int w, int h, const float *rgb, void **out) { FH_TRY *out = new EnvironmentMap(w, h, rgb); FH_CATCH }
+int fh_envmap_destroy(void *e) { delete (EnvironmentMap *)e; return 0; }
+int fh_envmap_dims(void *e, int *w, int *h) { *w = ((EnvironmentMap *)e)->getWidth(); *h = ((EnvironmentMap *)e)->getHeight(); return 0; }
+int fh_envmap_get(void *e, float *rgb, float *prob, int *alias, float *pdf)
+{
+    FH_TRY
+    EnvironmentMap *m = (EnvironmentMap *)e; size_t n = (size_t)m->getWidth() * m->getHeight();
+    if (rgb) memcpy(rgb, m->getData(), n * 3 * 4);
+    if (prob) memcpy(prob, m->getProbTable(), n * 4);
+    if (alias) memcpy(alias, m->getAliasTable(), n * 4);
+    if (pdf) memcpy(pdf, m->getPdfTable(), n * 4);
+    FH_CATCH
+}
+
+} // extern "C"
