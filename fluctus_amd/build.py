@@ -1,0 +1,75 @@
+"""In-tree builds (no JIT caches): libfluctus_hip.so (hipcc, gfx950), libfluctus_host.so (g++),
+oracle/liboracle.so (g++), oracle/_ref (only where /root/reference exists)."""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fluctus_amd")
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-munsafe-fp-atomics", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd, cwd=ROOT):
+    print("[build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stdout.write(r.stdout)
+        raise RuntimeError(f"build failed: {' '.join(cmd)}")
+    return r.stdout
+
+
+def _headers():
+    return glob.glob(os.path.join(ROOT, "include", "*.h"))
+
+
+def build_host(force=False):
+    src = sorted(glob.glob(os.path.join(PKG, "host", "*.cpp")))
+    dep = src + glob.glob(os.path.join(PKG, "host", "*.hpp")) + _headers()
+    out = os.path.join(PKG, "libfluctus_host.so")
+    if force or _stale(out, dep):
+        _run(["g++"] + CXX_FLAGS + ["-fopenmp"] + src + ["-o", out, "-ldl"])
+    return out
+
+
+def build_oracle(force=False):
+    src = [os.path.join(ROOT, "oracle", "wf_oracle.cpp")]
+    out = os.path.join(ROOT, "oracle", "liboracle.so")
+    if force or _stale(out, src + _headers()):
+        _run(["g++"] + CXX_FLAGS + ["-ffp-contract=off", "-fopenmp"] + src + ["-o", out])
+    return out
+
+
+def build_ref(force=False):
+    """The reference's own kernels for x86-64 -- only where the reference checkout exists (this container)."""
+    if not os.path.isdir("/root/reference/src"):
+        return None
+    out = os.path.join(ROOT, "oracle", "_ref", "libfluctus_ref.so")
+    dep = glob.glob(os.path.join(ROOT, "oracle", "ref", "*"))
+    if force or _stale(out, dep):
+        _run(["make", "-C", os.path.join(ROOT, "oracle", "ref"), "-j8"])
+    return out
+
+
+def build_hip(force=False):
+    src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
+    dep = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + _headers()
+    out = os.path.join(PKG, "libfluctus_hip.so")
+    if force or _stale(out, dep):
+        hipcc = "/opt/rocm/bin/hipcc"
+        _run([hipcc] + [f for f in HIP_FLAGS if f] + src + ["-o", out])
+    return out
+
+
+def build_all(force=False):
+    return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]

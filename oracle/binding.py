@@ -29,15 +29,45 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
 
 
+class _Prefixed:
+    """Attribute access L.orc_xyz -> getattr(lib, prefix + 'xyz') so one class serves both libraries."""
+
+    def __init__(self, cdll, prefix):
+        self._l, self._p = cdll, prefix
+
+    def __getattr__(self, name):
+        assert name.startswith("orc_")
+        return getattr(self._l, self._p + name[4:])
+
+
+_ref_lib = None
+
+
+def ref_lib():
+    """oracle/_ref/libfluctus_ref.so: the reference's own kernels compiled for x86-64 (this container only)."""
+    global _ref_lib
+    if _ref_lib is None:
+        path = os.path.join(_HERE, "_ref", "libfluctus_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        _ref_lib = C.CDLL(path)
+    return _ref_lib
+
+
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libfluctus_ref.so"))
+
+
 class OracleContext:
     name = "oracle"
 
-    def __init__(self, num_tasks, threads=1):
-        self.L = lib()
+    def __init__(self, num_tasks, threads=1, _ref=False):
+        self.L = _Prefixed(ref_lib(), "ref_") if _ref else lib()
         self.h = C.c_void_p()
         self.num_tasks = int(num_tasks)
         assert self.L.orc_create(C.c_uint32(num_tasks), C.byref(self.h)) == 0
-        self.L.orc_set_threads(self.h, int(threads))
+        if not _ref:
+            self.L.orc_set_threads(self.h, int(threads))
         self.params = None
 
     def close(self):
@@ -117,3 +147,11 @@ class OracleContext:
                     shadow_inner=int(out[4]), shadow_tri=int(out[5]), shadow_rays=int(out[6]))
 
     def reset_stats(self): self.L.orc_reset_stats(self.h)
+
+
+class RefContext(OracleContext):
+    """Same interface, backed by the reference's own kernels (oracle/_ref)."""
+    name = "reference"
+
+    def __init__(self, num_tasks):
+        super().__init__(num_tasks, _ref=True)

@@ -1,0 +1,131 @@
+"""Pin the CPU oracle (oracle/wf_oracle.cpp) against the reference's OWN kernels.
+
+oracle/_ref/libfluctus_ref.so is the reference's wf_*.cl / mk_postprocess.cl compiled unmodified for
+x86-64 (oracle/ref/Makefile).  It exists only in the build container (needs /root/reference), so these
+tests skip elsewhere; the golden fixtures in tests/golden (made from the same build by
+scripts/make_golden.py) carry the pin to the GPU box.
+
+Method: LOCKSTEP.  Both implementations start every kernel from the SAME state (the oracle's state,
+queues and counters are imported into the reference context), run one kernel, and are compared.
+Integers (hit index, matId, seeds, flags, queue contents in canonical order, counters) must be exact;
+floats within rtol 1e-5 (1e-4 downstream of atan2/acos/native_* as stated in SURVEY 8(c)), which is the
+gap between include/flx_math.h and libm.
+"""
+import numpy as np
+import pytest
+import common
+from common import COL, Q
+from fluctus_amd import host, wire, driver
+from oracle.binding import OracleContext, ref_available
+
+pytestmark = [pytest.mark.ref, pytest.mark.skipif(not ref_available(), reason="oracle/_ref not built (needs /root/reference)")]
+
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def _pair(d, p, n, env=None):
+    from oracle.binding import RefContext
+    a, b = OracleContext(n), RefContext(n)
+    for c in (a, b):
+        c.upload_scene(d)
+        if env is not None:
+            c.upload_envmap(env)
+        c.set_params(p)
+        driver.reset_renderer(c)
+    return a, b
+
+
+def _step(a, b, name, fn, rtol=RTOL, atol=ATOL, skip=(), undefined_pdfw=False):
+    common.sync(b, a)
+    fn(a)
+    fn(b)
+    ca, cb = a.get_counters(), b.get_counters()
+    assert (ca == cb).all(), f"{name}: counters {ca} vs {cb}"
+    for q in range(8):
+        n = int(ca[q])
+        qa, qb = a.queue_read(q)[:n], b.queue_read(q)[:n]
+        assert np.array_equal(qa, qb), f"{name}: queue {q} order differs"
+    sa, sb = a.state_export(), b.state_export()
+    mask = None
+    if undefined_pdfw:
+        # reference leaves pdfW uninitialised when the glossy sampler rejects (glossy.cl:59-60); T is 0 there
+        mask = ~((sa[COL.T] == 0) & (sa[COL.T + 1] == 0) & (sa[COL.T + 2] == 0))
+    fails = common.state_diff(sa, sb, rtol, atol, skip_cols=skip, mask=mask)
+    assert not fails, f"{name}: " + "; ".join(fails[:5])
+
+
+def _iterate(a, b, npix, iters, rtol=RTOL, atol=ATOL, mat_rtol=None):
+    for it in range(iters):
+        _step(a, b, f"it{it} logic", lambda c: c.wf_logic(False), rtol, atol)
+        _step(a, b, f"it{it} raygen", lambda c: c.wf_raygen(), rtol, atol)
+        _step(a, b, f"it{it} materials", lambda c: c.wf_materials(), mat_rtol or rtol, atol, undefined_pdfw=True)
+        cnt = a.get_counters().copy()
+        _step(a, b, f"it{it} extend", lambda c: c.wf_extend(), rtol, atol)
+        _step(a, b, f"it{it} shadow", lambda c: c.wf_shadow(), rtol, atol)
+        for c in (a, b):
+            c.clear_queues()
+            c.pixel_index_update(npix, int(cnt[0]))
+    pa, pb = a.read_pixels(0), b.read_pixels(0)
+    assert np.array_equal(pa[:, 3], pb[:, 3])
+    assert np.allclose(pa, pb, rtol=1e-4, atol=1e-5)
+    for c in (a, b):
+        c.postprocess()
+    assert np.allclose(a.read_pixels(1), b.read_pixels(1), rtol=1e-4, atol=1e-5)
+
+
+def test_teapot_area_light_single_queue():
+    """Config 1 of BASELINE.json: teapot.ply, Lambertian, area light, 4 bounces."""
+    d = host.load_scene(common.REF_ASSETS + "/teapot.ply")
+    host.build_bvh(d, "sbvh")
+    w = h = 96
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    p["maxBounces"] = 4
+    a, b = _pair(d, p, w * h)
+    _iterate(a, b, w * h, 10)
+
+
+@pytest.mark.parametrize("area,env,expl,impl,sep,roulette", [
+    (1, 0, 1, 1, 1, 0),
+    (0, 1, 1, 1, 1, 0),
+    (1, 1, 1, 1, 0, 1),
+    (1, 1, 1, 0, 1, 0),
+    (1, 1, 0, 1, 1, 0),
+    (0, 0, 1, 1, 1, 1),
+])
+def test_all_bsdfs_flag_matrix(area, env, expl, impl, sep, roulette):
+    """All six BSDFs + textures + normal map, env-map MIS / area light NEE, separate vs single queue, RR."""
+    d = common.mixed_material_scene()
+    w, h, n = 64, 48, 4096
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=area, useEnvMap=env, sampleExpl=expl, sampleImpl=impl,
+                            wfSeparateQueues=sep, useRoulette=roulette, envMapStrength=1.5)
+    e = host.synthetic_sky(64, 32)
+    a, b = _pair(d, p, n, env=e)
+    # env-map lookups and the GGX lobe sit downstream of atan2/acos/sin/cos: SURVEY 8(c) allows 1e-4 there
+    # ... and GGX D/pdf for small alpha amplify ulp-level differences of sin/cos/atan2 (observed <= 2e-4 rel)
+    _iterate(a, b, w * h, 9, rtol=1e-4, atol=1e-5, mat_rtol=1e-3)
+
+
+def test_first_frame_preview_path():
+    """Tracer::update iteration 0: reset, raygen, extend, then 3 logic rounds with firstIteration=1, 2 bounces."""
+    d = common.simple_scene()
+    w, h, n = 40, 30, 2048       # numTasks > numPixels exercises maxId = min(w*h, numTasks)
+    p = common.scene_params(d, w, h, maxBounces=6)
+    a, b = _pair(d, p, n)
+    p2 = p.copy()
+    p2["maxBounces"] = 2
+    for c in (a, b):
+        c.set_params(p2)
+        c.pixel_index_reset()
+    _step(a, b, "reset", lambda c: c.wf_reset())
+    _step(a, b, "raygen0", lambda c: c.wf_raygen())
+    _step(a, b, "extend0", lambda c: c.wf_extend())
+    for c in (a, b):
+        c.clear_queues()
+    for r in range(3):
+        _step(a, b, f"r{r} logic", lambda c: c.wf_logic(True))
+        _step(a, b, f"r{r} raygen", lambda c: c.wf_raygen())
+        _step(a, b, f"r{r} materials", lambda c: c.wf_materials())
+        _step(a, b, f"r{r} extend", lambda c: c.wf_extend())
+        _step(a, b, f"r{r} shadow", lambda c: c.wf_shadow())
+        for c in (a, b):
+            c.clear_queues()
