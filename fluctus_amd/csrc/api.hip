@@ -1,0 +1,461 @@
+// api.hip -- the C ABI of libfluctus_hip.so (include/fluctus_hip.h): context, uploads with the
+// CDNA4 re-layout of the BVH, asynchronous kernel sequencing on one HIP stream, measurement hooks.
+#include "flx_device.h"
+#include "../../include/fluctus_hip.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+
+namespace flxd {
+void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
+void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
+void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
+void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
+void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
+void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
+void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
+void launch_state_export(hipStream_t, const State &, float *);
+void launch_state_import(hipStream_t, const State &, const float *);
+}
+
+using namespace flxd;
+
+static thread_local std::string g_create_error;
+
+struct PendingCounters { void *user; int slot; };
+struct PendingEvent { int kernel; hipEvent_t a, b; };
+
+struct flx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t numTasks = 0;
+    std::string err;
+    State st {};
+    Queues qs {};
+    Scene sc {};
+    Frame fr {};
+    flx_render_params params {};
+    bool haveParams = false;
+    uint32_t hostPixelIdx = 0;
+    // logic aux
+    uint8_t *member = nullptr; uint32_t *blockCounts = nullptr, *blockOffsets = nullptr;
+    // trace aux
+    uint32_t *spill = nullptr;
+    unsigned long long *stats = nullptr;   // device, 7 counters
+    bool statsOn = false;
+    int xcdRemap = 1;
+    // owned device allocations
+    std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs;
+    // async counter read-back
+    flx_queue_counters *pinned = nullptr; int pinnedSlots = 64, nextSlot = 0;
+    uint32_t *pinnedIdx = nullptr; int nextIdxSlot = 0;
+    std::vector<PendingCounters> pending;
+    // profiling
+    bool profile = false;
+    std::vector<PendingEvent> events;
+    std::vector<hipEvent_t> eventPool;
+    double kMs[FLX_K_COUNT] = {0}; uint64_t kLaunches[FLX_K_COUNT] = {0};
+};
+
+#define HIPCHK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return 1; } } while (0)
+#define NEED(c, cond, msg) do { if (!(cond)) { (c)->err = msg; return 1; } } while (0)
+
+template <class T> static int dalloc(flx_ctx *c, std::vector<void *> &own, T **p, size_t count)
+{
+    void *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, (count ? count : 1) * sizeof(T)));
+    own.push_back(d);
+    *p = (T *)d;
+    return 0;
+}
+static void freeAll(std::vector<void *> &v) { for (void *p : v) (void)hipFree(p); v.clear(); }
+
+static hipEvent_t getEvent(flx_ctx *c)
+{
+    if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ScopedTimer {
+    flx_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(flx_ctx *c_, int k_) : c(c_), k(k_) { if (c->profile) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, c->stream); } }
+    ~ScopedTimer() { if (c->profile) { (void)hipEventRecord(b, c->stream); c->events.push_back({k, a, b}); } }
+};
+
+static uint32_t localPixels(const flx_ctx *c)
+{
+    uint32_t npix = c->params.width * c->params.height;
+    if (npix <= c->fr.rank) return 1;
+    return (npix - c->fr.rank + c->fr.nranks - 1) / c->fr.nranks;
+}
+
+static int allocFrame(flx_ctx *c)
+{
+    uint32_t lp = localPixels(c);
+    if (lp == c->fr.localPixels && c->fr.pixels) return 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    freeAll(c->frameAllocs);
+    HIPCHK(c, dalloc(c, c->frameAllocs, &c->fr.pixels, (size_t)lp * 4) ? hipErrorOutOfMemory : hipSuccess);
+    HIPCHK(c, dalloc(c, c->frameAllocs, &c->fr.preview, (size_t)lp * 4) ? hipErrorOutOfMemory : hipSuccess);
+    HIPCHK(c, hipMemsetAsync(c->fr.pixels, 0, (size_t)lp * 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->fr.preview, 0, (size_t)lp * 16, c->stream));
+    c->fr.localPixels = lp;
+    return 0;
+}
+
+extern "C" {
+
+const char *flx_last_error(flx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
+{
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_error = "flx_create: no HIP device available (libfluctus_hip.so has no CPU fallback)"; return 1; }
+    if (device < 0 || device >= ndev) { g_create_error = "flx_create: bad device index"; return 1; }
+    if (num_tasks == 0) { g_create_error = "flx_create: num_tasks must be > 0"; return 1; }
+    flx_ctx *c = new flx_ctx();
+    c->device = device; c->numTasks = num_tasks;
+    auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    const size_t N = num_tasks;
+    c->st.numTasks = num_tasks;
+    for (int r = 0; r < S_NUM_REC; r++) {
+        if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
+        (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
+    }
+    if (dalloc(c, c->fixedAllocs, &c->st.blocked, N) || dalloc(c, c->fixedAllocs, &c->st.pickProb, N) || dalloc(c, c->fixedAllocs, &c->st.firstDiffuse, N))
+        return fail("hipMalloc(state)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->st.blocked, 0, N * 4, c->stream); (void)hipMemsetAsync(c->st.pickProb, 0, N * 4, c->stream); (void)hipMemsetAsync(c->st.firstDiffuse, 0, N * 4, c->stream);
+    for (int q = 0; q < FLX_NUM_QUEUES; q++) {
+        if (dalloc(c, c->fixedAllocs, &c->qs.q[q], N)) return fail("hipMalloc(queue)", hipErrorOutOfMemory);
+        (void)hipMemsetAsync(c->qs.q[q], 0, N * 4, c->stream);
+    }
+    if (dalloc(c, c->fixedAllocs, &c->qs.counters, 8)) return fail("hipMalloc(counters)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->qs.counters, 0, 32, c->stream);
+    const uint32_t blocks = (num_tasks + 255) / 256;
+    if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * blocks) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * blocks))
+        return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)32 * blocks * 256)) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->stats, 8)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->stats, 0, 64, c->stream);
+    if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream);
+    c->fr.rank = 0; c->fr.nranks = 1; c->fr.localPixels = 0;
+    if ((e = hipHostMalloc((void **)&c->pinned, sizeof(flx_queue_counters) * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void **)&c->pinnedIdx, sizeof(uint32_t) * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
+    // dummy 1x1 black environment map (reference: CLContext::setupScene, src/clcontext.cpp:513-518)
+    {
+        float4 *rgba; float *prob, *pdf; int *alias;
+        if (dalloc(c, c->envAllocs, &rgba, 1) || dalloc(c, c->envAllocs, &prob, 1) || dalloc(c, c->envAllocs, &pdf, 1) || dalloc(c, c->envAllocs, &alias, 1))
+            return fail("hipMalloc(env)", hipErrorOutOfMemory);
+        float one = 1.0f;
+        (void)hipMemsetAsync(rgba, 0, 16, c->stream); (void)hipMemsetAsync(alias, 0, 4, c->stream);
+        (void)hipMemcpyAsync(prob, &one, 4, hipMemcpyHostToDevice, c->stream); (void)hipMemcpyAsync(pdf, &one, 4, hipMemcpyHostToDevice, c->stream);
+        c->sc.envRGBA = rgba; c->sc.probTable = prob; c->sc.pdfTable = pdf; c->sc.aliasTable = alias; c->sc.envW = c->sc.envH = 1;
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    *out = c;
+    return 0;
+}
+
+int flx_destroy(flx_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeAll(c->sceneAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->fixedAllocs);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
+    for (auto &ev : c->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto e : c->eventPool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+uint32_t flx_num_tasks(flx_ctx *c) { return c->numTasks; }
+void *flx_stream(flx_ctx *c) { return (void *)c->stream; }
+
+// ---- scene upload: reference wire arrays -> traversal layout -------------------------------
+int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t *indices, size_t nidx,
+                     const void *nodesv, size_t nnodes, const void *materials, size_t nmat,
+                     const void *texdesc, size_t ntex, const uint8_t *texdata, size_t texbytes)
+{
+    NEED(c, trisv && ntris && indices && nidx && nodesv && nnodes, "flx_upload_scene: empty scene");
+    NEED(c, materials && nmat, "flx_upload_scene: at least the default material is required");
+    HIPCHK(c, hipSetDevice(c->device));
+    const flx_triangle *tris = (const flx_triangle *)trisv;
+    const flx_node *nodes = (const flx_node *)nodesv;
+
+    // 1. leaf triangle records, in index-list order (a leaf is a contiguous run of the list)
+    std::vector<TriRec> trirecs(nidx);
+    for (size_t s = 0; s < nidx; s++) {
+        NEED(c, indices[s] < ntris, "flx_upload_scene: index out of range");
+        const flx_triangle &t = tris[indices[s]];
+        int idx = (int)indices[s], zero = 0;
+        float fi, fz; memcpy(&fi, &idx, 4); memcpy(&fz, &zero, 4);
+        trirecs[s].a = make_float4(t.v0.p.x, t.v0.p.y, t.v0.p.z, fi);
+        trirecs[s].b = make_float4(t.v1.p.x, t.v1.p.y, t.v1.p.z, fz);
+        trirecs[s].c = make_float4(t.v2.p.x, t.v2.p.y, t.v2.p.z, 0.0f);
+    }
+    // 2. inner-node records: both child boxes + refs; DFS numbering of inner nodes only
+    std::vector<int32_t> innerId(nnodes, -1);
+    uint32_t ninner = 0;
+    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) innerId[i] = (int32_t)ninner++;
+    auto childRef = [&](uint32_t ni, bool &ok) -> uint32_t {
+        if (ni >= nnodes) { ok = false; return 0; }
+        const flx_node &n = nodes[ni];
+        if (n.nPrims == 0) return (uint32_t)innerId[ni];
+        if ((size_t)n.iStartOrRight + n.nPrims > nidx) { ok = false; return 0; }
+        int cnt = n.nPrims; float fc; memcpy(&fc, &cnt, 4);
+        trirecs[n.iStartOrRight].b.w = fc;               // leaf count lives in the run's first record
+        return FLX_LEAF_BIT | n.iStartOrRight;
+    };
+    std::vector<BNode> bnodes(ninner ? ninner : 1);
+    bool ok = true;
+    if (ninner == 0) {
+        // the whole scene is one leaf: synthetic root whose two children are that leaf
+        BNode &b = bnodes[0];
+        const flx_node &n = nodes[0];
+        const float mn[3] = {n.bmin.x, n.bmin.y, n.bmin.z}, mx[3] = {n.bmax.x, n.bmax.y, n.bmax.z};
+        for (int k = 0; k < 3; k++) { b.lmin[k] = b.rmin[k] = mn[k]; b.lmax[k] = b.rmax[k] = mx[k]; }
+        b.left = b.right = childRef(0, ok); b.pad[0] = b.pad[1] = 0;
+    } else {
+        for (size_t i = 0; i < nnodes; i++) {
+            if (nodes[i].nPrims != 0) continue;
+            BNode &b = bnodes[innerId[i]];
+            uint32_t l = (uint32_t)i + 1, r = nodes[i].iStartOrRight;
+            NEED(c, l < nnodes && r < nnodes, "flx_upload_scene: child index out of range");
+            const flx_node &ln = nodes[l], &rn = nodes[r];
+            b.lmin[0] = ln.bmin.x; b.lmin[1] = ln.bmin.y; b.lmin[2] = ln.bmin.z; b.lmax[0] = ln.bmax.x; b.lmax[1] = ln.bmax.y; b.lmax[2] = ln.bmax.z;
+            b.rmin[0] = rn.bmin.x; b.rmin[1] = rn.bmin.y; b.rmin[2] = rn.bmin.z; b.rmax[0] = rn.bmax.x; b.rmax[1] = rn.bmax.y; b.rmax[2] = rn.bmax.z;
+            b.left = childRef(l, ok); b.right = childRef(r, ok); b.pad[0] = b.pad[1] = 0;
+        }
+    }
+    NEED(c, ok, "flx_upload_scene: malformed node array");
+    // 3. shading records per ORIGINAL triangle index
+    std::vector<ShadeRec> shade(ntris);
+    for (size_t i = 0; i < ntris; i++) {
+        const flx_triangle &t = tris[i];
+        float fm; int m = t.matId; memcpy(&fm, &m, 4);
+        NEED(c, m >= 0 && (size_t)m < nmat, "flx_upload_scene: triangle material id out of range");
+        shade[i].a = make_float4(t.v0.n.x, t.v0.n.y, t.v0.n.z, t.v0.t.x);
+        shade[i].b = make_float4(t.v1.n.x, t.v1.n.y, t.v1.n.z, t.v0.t.y);
+        shade[i].c = make_float4(t.v2.n.x, t.v2.n.y, t.v2.n.z, t.v1.t.x);
+        shade[i].d = make_float4(t.v1.t.y, t.v2.t.x, t.v2.t.y, fm);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    freeAll(c->sceneAllocs);
+    BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX;
+    if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size()) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
+        dalloc(c, c->sceneAllocs, &dTri, ntris) || dalloc(c, c->sceneAllocs, &dM, nmat) || dalloc(c, c->sceneAllocs, &dD, ntex) || dalloc(c, c->sceneAllocs, &dX, texbytes + 4))
+        return 1;
+    HIPCHK(c, hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dS, shade.data(), shade.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dTri, tris, ntris * sizeof(flx_triangle), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dM, materials, nmat * sizeof(flx_material), hipMemcpyHostToDevice));
+    if (ntex) HIPCHK(c, hipMemcpy(dD, texdesc, ntex * sizeof(flx_texdesc), hipMemcpyHostToDevice));
+    if (texbytes) HIPCHK(c, hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
+    c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
+    c->sc.rootRef = 0;
+    return 0;
+}
+
+int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *prob, const int *alias, const float *pdf)
+{
+    NEED(c, rgb && prob && alias && pdf && w > 0 && h > 0, "flx_upload_envmap: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    std::vector<float4> rgba(n);
+    for (size_t i = 0; i < n; i++) rgba[i] = make_float4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 1.0f);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    freeAll(c->envAllocs);
+    float4 *dR; float *dP, *dF; int *dA;
+    if (dalloc(c, c->envAllocs, &dR, n) || dalloc(c, c->envAllocs, &dP, n) || dalloc(c, c->envAllocs, &dF, n) || dalloc(c, c->envAllocs, &dA, n)) return 1;
+    HIPCHK(c, hipMemcpy(dR, rgba.data(), n * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dP, prob, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dF, pdf, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dA, alias, n * 4, hipMemcpyHostToDevice));
+    c->sc.envRGBA = dR; c->sc.probTable = dP; c->sc.pdfTable = dF; c->sc.aliasTable = dA; c->sc.envW = w; c->sc.envH = h;
+    return 0;
+}
+
+int flx_set_params(flx_ctx *c, const void *p240)
+{
+    NEED(c, p240, "flx_set_params: null");
+    HIPCHK(c, hipSetDevice(c->device));
+    memcpy(&c->params, p240, sizeof(flx_render_params));   // kernels receive the struct by value at launch = in-order semantics
+    NEED(c, c->params.width > 0 && c->params.height > 0, "flx_set_params: zero-sized framebuffer");
+    c->haveParams = true;
+    return allocFrame(c);
+}
+
+int flx_set_partition(flx_ctx *c, uint32_t rank, uint32_t nranks)
+{
+    NEED(c, nranks >= 1 && rank < nranks, "flx_set_partition: bad rank");
+    c->fr.rank = rank; c->fr.nranks = nranks;
+    return c->haveParams ? allocFrame(c) : 0;
+}
+uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
+
+#define READY(c) do { NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+#define LAUNCHED(c) HIPCHK(c, hipGetLastError())
+
+int flx_wf_reset(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_raygen(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_extend(flx_ctx *c)
+{
+    READY(c);
+    { ScopedTimer t(c, FLX_K_EXTEND); launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap); }
+    LAUNCHED(c); return 0;
+}
+int flx_wf_shadow(flx_ctx *c)
+{
+    READY(c);
+    { ScopedTimer t(c, FLX_K_SHADOW); launch_shadow(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap); }
+    LAUNCHED(c); return 0;
+}
+int flx_wf_logic(flx_ctx *c, int first)
+{
+    READY(c);
+    { ScopedTimer t(c, FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first); }
+    LAUNCHED(c); return 0;
+}
+int flx_wf_materials(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); } LAUNCHED(c); return 0; }
+int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
+
+int flx_clear_queues(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+
+int flx_get_counters_async(flx_ctx *c, void *out32)
+{
+    NEED(c, out32, "flx_get_counters_async: null");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((int)c->pending.size() >= c->pinnedSlots) { c->err = "too many outstanding counter reads; call flx_finish"; return 1; }
+    int slot = c->nextSlot; c->nextSlot = (c->nextSlot + 1) % c->pinnedSlots;
+    HIPCHK(c, hipMemcpyAsync(&c->pinned[slot], c->qs.counters, 32, hipMemcpyDeviceToHost, c->stream));
+    c->pending.push_back({out32, slot});
+    return 0;
+}
+
+int flx_finish(flx_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
+    c->pending.clear();
+    for (auto &ev : c->events) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { c->kMs[ev.kernel] += ms; c->kLaunches[ev.kernel]++; }
+        c->eventPool.push_back(ev.a); c->eventPool.push_back(ev.b);
+    }
+    c->events.clear();
+    return 0;
+}
+
+int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
+{
+    NEED(c, npix > 0, "flx_pixel_index_update: zero pixels");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->hostPixelIdx = (uint32_t)(((uint64_t)c->hostPixelIdx + nnew) % npix);
+    int slot = c->nextIdxSlot; c->nextIdxSlot = (c->nextIdxSlot + 1) % c->pinnedSlots;
+    c->pinnedIdx[slot] = c->hostPixelIdx;
+    HIPCHK(c, hipMemcpyAsync(c->fr.currPixelIdx, &c->pinnedIdx[slot], 4, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int flx_pixel_index_reset(flx_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    c->hostPixelIdx = 0;
+    HIPCHK(c, hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream));
+    return 0;
+}
+
+int flx_read_pixels(flx_ctx *c, int which, float *out)
+{
+    NEED(c, c->fr.pixels && out, "flx_read_pixels: no framebuffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, which == 0 ? c->fr.pixels : c->fr.preview, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_copy_pixels_to_device(flx_ctx *c, void *dst)
+{
+    NEED(c, c->fr.pixels && dst, "flx_copy_pixels_to_device: no framebuffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+// ---- measurement
+int flx_profile_enable(flx_ctx *c, int on) { c->profile = on != 0; return 0; }
+int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
+int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
+int flx_trace_stats_enable(flx_ctx *c, int on) { c->statsOn = on != 0; return 0; }
+int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out7, c->stats, 56, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_trace_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 64, c->stream)); return 0; }
+
+// ---- test hooks
+int flx_state_export(flx_ctx *c, float *out)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
+    HIPCHK(c, hipMalloc((void **)&d, bytes));
+    launch_state_export(c->stream, c->st, d);
+    hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return 0;
+}
+int flx_state_import(flx_ctx *c, const float *in)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
+    HIPCHK(c, hipMalloc((void **)&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_state_import(c->stream, c->st, d); e = hipStreamSynchronize(c->stream); }
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return 0;
+}
+int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
+{
+    NEED(c, q >= 0 && q < FLX_NUM_QUEUES, "bad queue id");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->qs.q[q], (size_t)c->numTasks * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
+{
+    NEED(c, q >= 0 && q < FLX_NUM_QUEUES && n <= c->numTasks, "bad queue id / length");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->qs.q[q], in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_set_counters(flx_ctx *c, const void *in32)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->qs.counters, in32, 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_set_option(flx_ctx *c, const char *name, int value)
+{
+    if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
+    c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
+    return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+// flx_device.h -- device-side data layout of libfluctus_hip.so (gfx950 / CDNA4 only).
+//
+// PATH STATE.  The reference keeps 64 four-byte SoA columns per path (256 B, 11 of them dead
+// padding; src/geom.h:199-236) and gathers them one dword at a time through the index queues.
+// Here the state is twelve 16-byte records per path ("SoA of float4") + two scalar columns =
+// 200 B/path, grouped by which kernel reads/writes them together, so that every access --
+// direct (logic: gid = thread) or indirect (queue[gid]) -- is one dwordx4 per lane:
+//
+//   ORIG   {orig.xyz, lastPdfW}          DIR    {dir.xyz, pathLen}
+//   HITP   {P.xyz, t}                    HITN   {N.xyz, flags: bit0 areaLightHit, bit1 backfaceHit}
+//   HITUV  {u, v, i, matId}              THR    {T.xyz, seed}
+//   EI     {Ei.xyz, pixelIndex}          SHO    {shadowOrig.xyz, shadowRayLen}
+//   SHD    {shadowDir.xyz, lastPdfDirect}  LBSDF {lastBsdf.xyz, lastPdfImplicit}
+//   LEMIT  {lastEmission.xyz, lastCosTh} LT     {lastT.xyz, lastSpecular}
+//   scalars: shadowRayBlocked (u32), lastLightPickProb (f32), firstDiffuseHit (u32, export only)
+//
+// BVH.  Uploaded in the reference's wire format (48-B nodes with one box each, 160-B triangles),
+// re-laid out for traversal: one 64-B record per INNER node holding BOTH child boxes and both
+// child references (one cache line per visit instead of 48 B + 2 x 32 B), 48-B position-only
+// triangle records in leaf order (leaf = contiguous run, count stored in the run's first record),
+// and a 64-B shading record per triangle (normals, uvs, matId) read once per ray after traversal.
+// Tree topology, child order and leaf order are the reference's, so ties resolve identically.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/fluctus_wire.h"
+#include "../../include/flx_math.h"
+
+namespace flxd {
+
+using namespace flx;
+
+enum { S_ORIG = 0, S_DIR, S_HITP, S_HITN, S_HITUV, S_THR, S_EI, S_SHO, S_SHD, S_LBSDF, S_LEMIT, S_LT, S_NUM_REC };
+
+struct State {
+    float4 *rec[S_NUM_REC];       // each numTasks float4
+    uint32_t *blocked;            // shadowRayBlocked
+    float *pickProb;              // lastLightPickProb
+    uint32_t *firstDiffuse;       // carried for export parity only
+    uint32_t numTasks;
+};
+
+struct Queues {
+    uint32_t *q[FLX_NUM_QUEUES];
+    uint32_t *counters;           // 8 x u32 (flx_queue_counters)
+};
+
+#define FLX_LEAF_BIT 0x80000000u
+
+struct BNode {                    // 64 B, 64-B aligned
+    float lmin[3], lmax[3];       // left child box
+    float rmin[3], rmax[3];       // right child box
+    uint32_t left, right;         // inner: BNode index; leaf: FLX_LEAF_BIT | first triangle slot
+    uint32_t pad[2];
+};
+
+struct TriRec {                   // 48 B: three float4
+    float4 a;                     // v0.xyz, triangle index (int bits)
+    float4 b;                     // v1.xyz, leaf count in the first record of a leaf run (int bits)
+    float4 c;                     // v2.xyz, unused
+};
+
+struct ShadeRec {                 // 64 B: four float4
+    float4 a;                     // n0.xyz, uv0.x
+    float4 b;                     // n1.xyz, uv0.y
+    float4 c;                     // n2.xyz, uv1.x
+    float4 d;                     // uv1.y, uv2.x, uv2.y, matId (int bits)
+};
+
+struct Scene {
+    const BNode *bnodes;
+    const TriRec *trirecs;
+    const ShadeRec *shade;
+    const flx_triangle *tris;     // reference-layout triangles (tangent frames for normal maps only)
+    const flx_material *materials;
+    const flx_texdesc *texdesc;
+    const uint8_t *texdata;
+    uint32_t rootRef;             // BNode 0 (inner) -- tiny scenes get a synthetic root
+    // environment map
+    const float4 *envRGBA;
+    const float *probTable, *pdfTable;
+    const int *aliasTable;
+    int envW, envH;
+};
+
+struct Frame {                    // framebuffers + cursor + partition
+    float *pixels;                // float4 per local pixel (rgb sum, sample count)
+    float *preview;
+    uint32_t *currPixelIdx;       // device copy of the pixel cursor
+    uint32_t rank, nranks;
+    uint32_t localPixels;
+};
+
+__device__ __forceinline__ f3 ld3(const float4 &v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float4 mk4u(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
+__device__ __forceinline__ f3 V(const flx_vec3 &v) { return mk3(v.x, v.y, v.z); }
+
+// wave64 helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Wave-aggregated queue append: one atomic per wave, slots handed out by ballot prefix.
+// (reference: atomicIncAll/atomicIncMasked, src/utils.cl:328-358; NVIDIA-only warp aggregation in
+// src/ptx_asm.cl:92-111 -- here it is the only path).  Slot order within the queue is not
+// observable for the extension queue.
+__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool pred)
+{
+    uint64_t mask = __ballot(pred);
+    uint32_t base = 0;
+    if (mask != 0ull) {
+        uint32_t n = (uint32_t)__popcll(mask);
+        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        if (lane_id() == leader) base = atomicAdd(counter, n);
+        base = __shfl(base, (int)leader, 64);
+    }
+    return base + mbcnt(mask);
+}
+
+} // namespace flxd

@@ -1,0 +1,280 @@
+// logic.hip -- the per-path state machine of the wavefront loop + deterministic queue building.
+//
+// Replaces reference kernel `logic` (src/wf_logic.cl:14-314) and its queue-append helpers
+// (src/wf_logic.cl:322-519, src/utils.cl:328-358).  Per path, in the reference's order: russian
+// roulette, zero-throughput termination, implicit environment / area-light hit with MIS, consume the
+// previous vertex' NEE sample if its shadow ray was unblocked, splat + regenerate on termination,
+// otherwise tangent-space normal, backface flip, next-event estimation (env-map alias sampling or
+// area-light sampling) and material-queue selection.
+//
+// Queue building is NOT a per-thread global atomic (reference, non-NVIDIA) and not an inline-PTX
+// warp aggregate (reference, NVIDIA): the kernel only records, per path, one byte of queue
+// membership and, per 256-path block, seven counts (wave64 ballot + popcount).  A one-block scan
+// turns the counts into offsets and a scatter kernel writes the queues with ballot/prefix ranks,
+// i.e. a STABLE compaction: queue order = ascending path id = the order sequential execution of
+// the reference produces.  Only the raygen queue's order is observable (pixel
+// assignment), and it makes device runs bit-reproducible.
+#include "flx_shading.h"
+
+namespace flxd {
+
+#define LOGIC_BLOCK 256
+// membership byte: bit0 raygen, bit1 shadow, bits 2..4 material queue (0 none, 1 diffuse, 2 glossy,
+// 3 ggx reflection, 4 ggx refraction, 5 delta)
+#define NUM_LISTS 7   // raygen, shadow, 5 material
+
+struct LogicAux {
+    uint8_t *member;          // numTasks
+    uint32_t *blockCounts;    // NUM_LISTS x numBlocks
+    uint32_t *blockOffsets;   // NUM_LISTS x numBlocks
+    uint32_t numBlocks;
+};
+
+__device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
+{
+    if (!separate) return 1u;                       // WF_SINGLE_MAT_QUEUE: everything in the diffuse queue
+    switch (type) {
+    case FLX_BXDF_DIFFUSE: return 1u;
+    case FLX_BXDF_GLOSSY: return 2u;
+    case FLX_BXDF_GGX_ROUGH_REFLECTION: return 3u;
+    case FLX_BXDF_GGX_ROUGH_DIELECTRIC: return 4u;
+    case FLX_BXDF_IDEAL_REFLECTION:
+    case FLX_BXDF_IDEAL_DIELECTRIC: return 5u;
+    default: return 0u;                             // reference prints an error and drops the path
+    }
+}
+
+__global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, uint32_t firstIteration)
+{
+    const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
+    uint32_t maxId = st.numTasks;
+    if (firstIteration) { uint32_t npix = p.width * p.height; maxId = npix < maxId ? npix : maxId; }
+    uint32_t member = 0u;
+
+    if (gid < maxId) {
+        const float4 thr = st.rec[S_THR][gid];
+        const float4 d4 = st.rec[S_DIR][gid];
+        const float4 o4 = st.rec[S_ORIG][gid];
+        const float4 hn = st.rec[S_HITN][gid];
+        const float4 huv = st.rec[S_HITUV][gid];
+        const float4 ei4 = st.rec[S_EI][gid];
+        uint32_t seed = __float_as_uint(thr.w);
+        const uint32_t len = __float_as_uint(d4.w);
+        const f3 rayOrig = ld3(o4), rayDir = ld3(d4);
+        const float lastPdfW = o4.w;
+        f3 T = ld3(thr);
+        f3 Ei = ld3(ei4);
+        f3 hitN = ld3(hn);
+        const uint32_t hflags = __float_as_uint(hn.w);
+        const int hitI = __float_as_int(huv.z), hitMat = __float_as_int(huv.w);
+        const f2 hitUV = mk2(huv.x, huv.y);
+        bool Tdirty = false;
+
+        // russian roulette (src/wf_logic.cl:60-69)
+        bool terminate = (len >= p.maxBounces + 1u);
+        if (terminate && p.useRoulette) {
+            float contProb = clampf(luminance(T), 0.01f, 0.5f);
+            terminate = (rand01(&seed) > contProb);
+            T = T / contProb;
+            Tdirty = true;
+        }
+        if (is_zero(T) || lastPdfW == 0.0f) terminate = true;        // :72-73
+
+        if (hitI < 0 && !terminate) {                                 // implicit environment sample, :84-107
+            float weight = 1.0f;
+            const bool lastSpecular = __float_as_uint(st.rec[S_LT][gid].w) != 0u;
+            f3 bg = mk3(0.0f);
+            if (p.useEnvMap && (len == 1u || p.sampleImpl)) bg = eval_env_dir(sc, rayDir) * p.envMapStrength;
+            if (p.sampleImpl && p.sampleExpl && p.useEnvMap && len > 1u && !lastSpecular) {
+                float lightPickProb = st.pickProb[gid];
+                float directPdfW = env_map_pdf(sc, rayDir);
+                weight = (lastPdfW * lightPickProb) / (lastPdfW * lightPickProb + directPdfW);
+            }
+            Ei = Ei + weight * T * bg;
+            terminate = true;
+        } else if (p.useAreaLight && (hflags & 1u) && !terminate) {   // implicit area-light sample, :111-131
+            float misWeight = 1.0f;
+            const bool lastSpecular = __float_as_uint(st.rec[S_LT][gid].w) != 0u;
+            const f3 hitP = ld3(st.rec[S_HITP][gid]);
+            if (p.sampleExpl && len > 1u && !lastSpecular) {
+                float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
+                float directPdfW = pdf_a_to_w(directPdfA, length(hitP - rayOrig), dot(normalize(-rayDir), hitN));
+                float lightPickProb = st.pickProb[gid];
+                misWeight = lastPdfW / (lastPdfW + directPdfW * lightPickProb);
+            }
+            Ei = Ei + T * misWeight * V(p.areaLight.E);
+            terminate = true;
+        }
+
+        // consume the light sample generated at the previous vertex (:135-156)
+        if (st.blocked[gid] == 0u) {
+            const float4 le = st.rec[S_LEMIT][gid];
+            const float4 lb = st.rec[S_LBSDF][gid];
+            const float4 lt = st.rec[S_LT][gid];
+            const float directPdfW = st.rec[S_SHD][gid].w;
+            const float lightPickProb = st.pickProb[gid];
+            const float cosTh = le.w, bsdfPdfW = lb.w;
+            float weight = 1.0f;
+            if (p.sampleImpl) weight = (directPdfW * lightPickProb) / (directPdfW * lightPickProb + bsdfPdfW);
+            f3 contrib = ld3(lb) * ld3(lt) * ld3(le) * weight * cosTh / (lightPickProb * directPdfW);
+            Ei = Ei + contrib;
+        }
+
+        if (terminate) {                                              // splat + regenerate, :163-177
+            if (len > 0u) {
+                float *px = fr.pixels + (size_t)__float_as_uint(ei4.w) * 4;
+                unsafeAtomicAdd(px + 0, Ei.x); unsafeAtomicAdd(px + 1, Ei.y);
+                unsafeAtomicAdd(px + 2, Ei.z); unsafeAtomicAdd(px + 3, 1.0f);
+            }
+            st.rec[S_EI][gid] = mk4(Ei, ei4.w);
+            st.rec[S_THR][gid] = mk4u(T, seed);
+            member = 1u;
+        } else {
+            const flx_material mat = sc.materials[hitMat];            // :180-184
+            hitN = tangent_space_normal(sc, hitN, hitUV, hitI, mat.map_N);
+            const bool backface = dot(hitN, rayDir) > 0.0f;
+            if (backface) hitN = hitN * -1.0f;
+            const f3 hitP = ld3(st.rec[S_HITP][gid]);
+            const f3 orig = hitP - 1e-3f * rayDir;
+            st.rec[S_HITN][gid] = mk4u(hitN, (hflags & 1u) | (backface ? 2u : 0u));   // :212-213
+
+            if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {    // next event estimation, :217-302
+                uint32_t den = p.useEnvMap + p.useAreaLight; if (den < 1u) den = 1u;
+                const float envMapProb = (float)p.useEnvMap / (float)den;
+                const bool useEnvMap = rand01(&seed) < envMapProb;
+                const bool useAreaLight = !useEnvMap && p.useAreaLight;
+                if (useEnvMap && p.useEnvMap) {
+                    f3 L; float directPdfW = 0.0f;
+                    sample_env_alias(sc, rand01(&seed), &L, &directPdfW);
+                    const float lenL = 2.0f * p.worldRadius;
+                    L = normalize(L);
+                    const float cosTh = fmaxf_(0.0f, dot(L, hitN));
+                    const f3 envMapLi = eval_env_dir(sc, L) * p.envMapStrength;
+                    st.rec[S_SHO][gid] = mk4(orig, lenL);
+                    st.rec[S_SHD][gid] = mk4(L, directPdfW);
+                    st.rec[S_LEMIT][gid] = mk4(envMapLi, cosTh);
+                    st.pickProb[gid] = envMapProb;
+                    member |= 2u;
+                }
+                if (useAreaLight) {
+                    const float lightPickProb = 1.0f - envMapProb;
+                    const float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
+                    f3 posL = V(p.areaLight.pos);
+                    const float r1 = 2.0f * rand01(&seed) - 1.0f;
+                    const float r2 = 2.0f * rand01(&seed) - 1.0f;
+                    posL = posL + r1 * p.areaLight.size.x * V(p.areaLight.right);
+                    posL = posL + r2 * p.areaLight.size.y * V(p.areaLight.up);
+                    f3 L = posL - orig;
+                    const float lenL = length(L) * 0.995f;
+                    L = normalize(L);
+                    const float cosLight = fmaxf_(dot(V(p.areaLight.N), -L), 0.0f);
+                    if (cosLight > 0.0f) {
+                        const float directPdfW = pdf_a_to_w(directPdfA, lenL, cosLight);
+                        const float cosTh = fmaxf_(0.0f, dot(L, hitN));
+                        st.rec[S_SHO][gid] = mk4(orig, lenL);
+                        st.rec[S_SHD][gid] = mk4(L, directPdfW);
+                        st.rec[S_LEMIT][gid] = mk4(V(p.areaLight.E), cosTh);
+                        st.pickProb[gid] = lightPickProb;
+                        member |= 2u;
+                    } else {
+                        st.blocked[gid] = 1u;
+                    }
+                }
+            }
+            st.rec[S_EI][gid] = mk4(Ei, ei4.w);
+            st.rec[S_THR][gid] = mk4u(T, seed);
+            (void)Tdirty;
+            member |= material_list(mat.type, p.wfSeparateQueues) << 2;
+        }
+    }
+
+    if (gid < st.numTasks) aux.member[gid] = (uint8_t)member;
+
+    // per-block counts of the 7 lists: ballot + popcount per wave, 4 waves per block
+    __shared__ uint32_t s_cnt[NUM_LISTS][LOGIC_BLOCK / 64];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t ml = member >> 2;
+    uint64_t b0 = __ballot(member & 1u), b1 = __ballot(member & 2u);
+    uint64_t m1 = __ballot(ml == 1u), m2 = __ballot(ml == 2u), m3 = __ballot(ml == 3u), m4 = __ballot(ml == 4u), m5 = __ballot(ml == 5u);
+    if ((threadIdx.x & 63u) == 0u) {
+        s_cnt[0][wave] = (uint32_t)__popcll(b0); s_cnt[1][wave] = (uint32_t)__popcll(b1);
+        s_cnt[2][wave] = (uint32_t)__popcll(m1); s_cnt[3][wave] = (uint32_t)__popcll(m2);
+        s_cnt[4][wave] = (uint32_t)__popcll(m3); s_cnt[5][wave] = (uint32_t)__popcll(m4); s_cnt[6][wave] = (uint32_t)__popcll(m5);
+    }
+    __syncthreads();
+    if (threadIdx.x < NUM_LISTS) {
+        uint32_t s = 0;
+        for (int w = 0; w < LOGIC_BLOCK / 64; w++) s += s_cnt[threadIdx.x][w];
+        aux.blockCounts[threadIdx.x * aux.numBlocks + blockIdx.x] = s;
+    }
+}
+
+// one block: exclusive scan of each list's per-block counts; totals are added to the queue counters
+__global__ __launch_bounds__(1024) void k_queue_scan(LogicAux aux, uint32_t *counters)
+{
+    __shared__ uint32_t s_part[1024];
+    const uint32_t listToCounter[NUM_LISTS] = {FLX_Q_RAYGEN, FLX_Q_SHADOW, FLX_Q_DIFFUSE, FLX_Q_GLOSSY, FLX_Q_GGX_REFL, FLX_Q_GGX_REFR, FLX_Q_DELTA};
+    const uint32_t nb = aux.numBlocks;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    for (int l = 0; l < NUM_LISTS; l++) {
+        const uint32_t *cnt = aux.blockCounts + (size_t)l * nb;
+        uint32_t *off = aux.blockOffsets + (size_t)l * nb;
+        const uint32_t base = counters[listToCounter[l]];
+        uint32_t lo = threadIdx.x * per, hi = lo + per; if (hi > nb) hi = nb;
+        uint32_t s = 0;
+        for (uint32_t i = lo; i < hi; i++) s += cnt[i];
+        s_part[threadIdx.x] = s;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {          // Hillis-Steele inclusive scan
+            uint32_t v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            s_part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = base + s_part[threadIdx.x] - s;
+        for (uint32_t i = lo; i < hi; i++) { off[i] = run; run += cnt[i]; }
+        __syncthreads();
+        if (threadIdx.x == 1023u) counters[listToCounter[l]] = base + s_part[1023];
+        __syncthreads();
+    }
+}
+
+// stable scatter: rank within block by wave ballots, block base from the scan
+__global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicAux aux, uint32_t numTasks)
+{
+    const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
+    const uint32_t member = gid < numTasks ? aux.member[gid] : 0u;
+    const uint32_t ml = member >> 2;
+    const uint32_t wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_cnt[NUM_LISTS][LOGIC_BLOCK / 64];
+    uint64_t bal[NUM_LISTS];
+    bal[0] = __ballot(member & 1u); bal[1] = __ballot(member & 2u);
+    bal[2] = __ballot(ml == 1u); bal[3] = __ballot(ml == 2u); bal[4] = __ballot(ml == 3u); bal[5] = __ballot(ml == 4u); bal[6] = __ballot(ml == 5u);
+    if ((threadIdx.x & 63u) == 0u)
+        for (int l = 0; l < NUM_LISTS; l++) s_cnt[l][wave] = (uint32_t)__popcll(bal[l]);
+    __syncthreads();
+    uint32_t *const outq[NUM_LISTS] = {qs.q[FLX_Q_RAYGEN], qs.q[FLX_Q_SHADOW], qs.q[FLX_Q_DIFFUSE], qs.q[FLX_Q_GLOSSY], qs.q[FLX_Q_GGX_REFL], qs.q[FLX_Q_GGX_REFR], qs.q[FLX_Q_DELTA]};
+    #pragma unroll
+    for (int l = 0; l < NUM_LISTS; l++) {
+        bool in = l == 0 ? (member & 1u) : l == 1 ? ((member & 2u) != 0u) : (ml == (uint32_t)(l - 1));
+        if (in) {
+            uint32_t r = aux.blockOffsets[(size_t)l * aux.numBlocks + blockIdx.x];
+            for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w];
+            r += mbcnt(bal[l]);
+            outq[l][r] = gid;
+        }
+    }
+}
+
+void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
+                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration)
+{
+    // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
+    uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
+    LogicAux aux{member, blockCounts, blockOffsets, blocks};
+    hipLaunchKernelGGL(k_logic, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+    hipLaunchKernelGGL(k_queue_scan, dim3(1), dim3(1024), 0, s, aux, qs.counters);
+    hipLaunchKernelGGL(k_queue_scatter, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, qs, aux, st.numTasks);
+}
+
+} // namespace flxd

@@ -1,0 +1,185 @@
+// misc.hip -- reset, camera-ray generation, post-process and the state import/export test hooks.
+//
+// Replaces reference kernels reset (src/wf_reset.cl:5-66), genRays (src/wf_raygen.cl:4-97) and
+// process (src/mk_postprocess.cl:7-55, src/tonemap.cl:3-26).
+#include "flx_shading.h"
+
+namespace flxd {
+
+#define MISC_BLOCK 256
+
+// Everything a (re)generated path starts from (src/wf_reset.cl:30-60 == src/wf_raygen.cl:77-96)
+__device__ __forceinline__ void init_path_state(const State &st, uint32_t gid, float shadowLen)
+{
+    st.rec[S_LBSDF][gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // lastBsdf, lastPdfImplicit
+    st.rec[S_LEMIT][gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // lastEmission, lastCosTh
+    st.rec[S_HITP][gid] = make_float4(0.0f, 0.0f, 0.0f, FLX_FLT_MAX); // EMPTY_HIT
+    st.rec[S_HITN][gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // N, areaLightHit = backfaceHit = 0
+    st.rec[S_HITUV][gid] = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+    st.pickProb[gid] = 1.0f;
+    st.blocked[gid] = 1u;
+    st.firstDiffuse[gid] = 0u;
+    // records with members reset() leaves alone are read-modify-written
+    float4 sho = st.rec[S_SHO][gid]; sho.w = shadowLen; st.rec[S_SHO][gid] = sho;
+    float4 shd = st.rec[S_SHD][gid]; shd.w = 0.0f; st.rec[S_SHD][gid] = shd;            // lastPdfDirect
+    float4 lt = st.rec[S_LT][gid]; lt.w = __uint_as_float(1u); st.rec[S_LT][gid] = lt;  // lastSpecular
+}
+
+__global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame fr, flx_render_params p, uint32_t n)
+{
+    const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    if (gid >= n) return;
+    if (gid < fr.localPixels) reinterpret_cast<float4 *>(fr.pixels)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (gid >= st.numTasks) return;
+    init_path_state(st, gid, 2.0f * p.worldRadius);
+    st.rec[S_EI][gid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));     // Ei, pixelIndex
+    st.rec[S_THR][gid] = mk4u(mk3(1.0f), gid);                                   // T, seed = gid
+    float4 o = st.rec[S_ORIG][gid]; o.w = 1.0f; st.rec[S_ORIG][gid] = o;          // lastPdfW
+    float4 d = st.rec[S_DIR][gid]; d.w = __uint_as_float(0u); st.rec[S_DIR][gid] = d;   // pathLen
+    qs.q[FLX_Q_RAYGEN][gid] = gid;
+    if (gid == 0) qs.counters[FLX_Q_RAYGEN] = st.numTasks;
+}
+
+__global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p)
+{
+    const uint32_t qlen = qs.counters[FLX_Q_RAYGEN];
+    const uint32_t gd = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    const bool active = gd < qlen;
+    uint32_t gid = 0;
+    if (active) {
+        gid = qs.q[FLX_Q_RAYGEN][gd];
+        uint32_t seed = __float_as_uint(st.rec[S_THR][gid].w);
+        // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
+        // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
+        const uint32_t localIdx = (*fr.currPixelIdx + gd) % fr.localPixels;
+        const uint32_t pixelIdx = localIdx * fr.nranks + fr.rank;
+        float x = (float)(pixelIdx % p.width);
+        float y = (float)(pixelIdx / p.width);
+        x += rand01(&seed);
+        y += rand01(&seed);
+        float NDCx = x / (float)p.width;
+        float NDCy = y / (float)p.height;
+        float SCRx = 2.0f * NDCx - 1.0f;
+        float SCRy = 2.0f * NDCy - 1.0f;
+        SCRx *= (float)p.width / (float)p.height;
+        const float scale = tanf_(0.5f * p.camera.fov * FLX_PI / 180.0f);
+        SCRx *= scale;
+        SCRy *= scale;
+        f3 rayOrig = V(p.camera.pos);
+        f3 rayTarget = rayOrig + V(p.camera.right) * SCRx + V(p.camera.up) * SCRy + V(p.camera.dir);
+        f3 rayDirection = normalize(rayTarget - rayOrig);
+        const f3 fp = V(p.camera.pos) + rayDirection * p.camera.focalDist;
+        const float sqrt_r = sqrtf(rand01(&seed));                 // uniformSampleDisk, src/utils.cl:75-80
+        const float th = FLX_2PI * rand01(&seed);
+        float sn, cs; sincosf_(th, &sn, &cs);
+        const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
+        rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
+        rayDirection = normalize(fp - rayOrig);
+
+        st.rec[S_ORIG][gid] = mk4(rayOrig, 1.0f);                  // lastPdfW = 1
+        st.rec[S_DIR][gid] = mk4u(rayDirection, 0u);               // pathLen = 0
+        st.rec[S_EI][gid] = mk4u(mk3(0.0f), localIdx);
+        st.rec[S_THR][gid] = mk4u(mk3(1.0f), seed);
+        init_path_state(st, gid, 2.0f * p.worldRadius);
+    }
+    const uint32_t slot = wave_append(&qs.counters[FLX_Q_EXTENSION], active);
+    if (active) qs.q[FLX_Q_EXTENSION][slot] = gid;
+}
+
+__device__ __forceinline__ f3 uc2_func(f3 x)
+{
+    const float A = 0.22f, B = 0.30f, C = 0.10f, D = 0.20f, E = 0.01f, Fq = 0.30f;
+    return ((x * (A * x + mk3(C * B)) + mk3(D * E)) / (x * (A * x + mk3(B)) + mk3(D * Fq))) - mk3(E / Fq);
+}
+
+__global__ __launch_bounds__(MISC_BLOCK) void k_postprocess(Frame fr, flx_render_params p)
+{
+    const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    if (gid >= fr.localPixels) return;
+    const float4 in = reinterpret_cast<const float4 *>(fr.pixels)[gid];
+    f3 col = ld3(in); float w = in.w;
+    if (w > 0.0f) { col = col / w; w = w / w; }
+    col = col * p.exposure;
+    if (p.tmOperator == 1u) col = col / (mk3(1.0f) + col);
+    if (p.tmOperator == 2u) col = uc2_func(2.0f * col) / uc2_func(mk3(11.2f));
+    col = pow3(col, 1.0f / 2.2f);
+    reinterpret_cast<float4 *>(fr.preview)[gid] = mk4(col, w);
+}
+
+// ---- test hooks: internal packed layout <-> reference 64-column SoA (src/geom.h:199-236)
+__global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *out)
+{
+    const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    const uint32_t N = st.numTasks;
+    if (gid >= N) return;
+    auto W = [&](int col, float v) { out[(size_t)col * N + gid] = v; };
+    auto W3 = [&](int col, float4 v) { W(col, v.x); W(col + 1, v.y); W(col + 2, v.z); W(col + 3, 0.0f); };
+    float4 r;
+    r = st.rec[S_ORIG][gid]; W3(FLX_COL_ORIG, r); W(FLX_COL_LAST_PDF_W, r.w);
+    r = st.rec[S_DIR][gid]; W3(FLX_COL_DIR, r); W(FLX_COL_PATH_LEN, r.w);
+    r = st.rec[S_SHO][gid]; W3(FLX_COL_SHADOW_ORIG, r); W(FLX_COL_SHADOW_LEN, r.w);
+    r = st.rec[S_SHD][gid]; W3(FLX_COL_SHADOW_DIR, r); W(FLX_COL_LAST_PDF_DIRECT, r.w);
+    r = st.rec[S_THR][gid]; W3(FLX_COL_T, r); W(FLX_COL_SEED, r.w);
+    r = st.rec[S_EI][gid]; W3(FLX_COL_EI, r); W(FLX_COL_PIXEL_INDEX, r.w);
+    r = st.rec[S_LBSDF][gid]; W3(FLX_COL_LAST_BSDF, r); W(FLX_COL_LAST_PDF_IMPLICIT, r.w);
+    r = st.rec[S_LEMIT][gid]; W3(FLX_COL_LAST_EMISSION, r); W(FLX_COL_LAST_COS_TH, r.w);
+    r = st.rec[S_LT][gid]; W3(FLX_COL_LAST_T, r); W(FLX_COL_LAST_SPECULAR, r.w);
+    r = st.rec[S_HITP][gid]; W3(FLX_COL_P, r); W(FLX_COL_HIT_T, r.w);
+    r = st.rec[S_HITN][gid]; W3(FLX_COL_N, r);
+    const uint32_t fl = __float_as_uint(r.w);
+    W(FLX_COL_AREA_LIGHT_HIT, __uint_as_float(fl & 1u)); W(FLX_COL_BACKFACE, __uint_as_float((fl >> 1) & 1u));
+    r = st.rec[S_HITUV][gid]; W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
+    W(FLX_COL_PHASE, 0.0f);
+    W(FLX_COL_SHADOW_BLOCKED, __uint_as_float(st.blocked[gid]));
+    W(FLX_COL_LAST_PICK_PROB, st.pickProb[gid]);
+    W(FLX_COL_FIRST_DIFFUSE, __uint_as_float(st.firstDiffuse[gid]));
+}
+
+__global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const float *in)
+{
+    const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    const uint32_t N = st.numTasks;
+    if (gid >= N) return;
+    auto R = [&](int col) { return in[(size_t)col * N + gid]; };
+    auto R4 = [&](int col, int wcol) { return make_float4(R(col), R(col + 1), R(col + 2), R(wcol)); };
+    st.rec[S_ORIG][gid] = R4(FLX_COL_ORIG, FLX_COL_LAST_PDF_W);
+    st.rec[S_DIR][gid] = R4(FLX_COL_DIR, FLX_COL_PATH_LEN);
+    st.rec[S_SHO][gid] = R4(FLX_COL_SHADOW_ORIG, FLX_COL_SHADOW_LEN);
+    st.rec[S_SHD][gid] = R4(FLX_COL_SHADOW_DIR, FLX_COL_LAST_PDF_DIRECT);
+    st.rec[S_THR][gid] = R4(FLX_COL_T, FLX_COL_SEED);
+    st.rec[S_EI][gid] = R4(FLX_COL_EI, FLX_COL_PIXEL_INDEX);
+    st.rec[S_LBSDF][gid] = R4(FLX_COL_LAST_BSDF, FLX_COL_LAST_PDF_IMPLICIT);
+    st.rec[S_LEMIT][gid] = R4(FLX_COL_LAST_EMISSION, FLX_COL_LAST_COS_TH);
+    st.rec[S_LT][gid] = R4(FLX_COL_LAST_T, FLX_COL_LAST_SPECULAR);
+    st.rec[S_HITP][gid] = R4(FLX_COL_P, FLX_COL_HIT_T);
+    const uint32_t fl = (__float_as_uint(R(FLX_COL_AREA_LIGHT_HIT)) ? 1u : 0u) | (__float_as_uint(R(FLX_COL_BACKFACE)) ? 2u : 0u);
+    st.rec[S_HITN][gid] = make_float4(R(FLX_COL_N), R(FLX_COL_N + 1), R(FLX_COL_N + 2), __uint_as_float(fl));
+    st.rec[S_HITUV][gid] = make_float4(R(FLX_COL_UV), R(FLX_COL_UV + 1), R(FLX_COL_HIT_I), R(FLX_COL_MAT_ID));
+    st.blocked[gid] = __float_as_uint(R(FLX_COL_SHADOW_BLOCKED));
+    st.pickProb[gid] = R(FLX_COL_LAST_PICK_PROB);
+    st.firstDiffuse[gid] = __float_as_uint(R(FLX_COL_FIRST_DIFFUSE));
+}
+
+void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
+{
+    uint32_t n = st.numTasks > fr.localPixels ? st.numTasks : fr.localPixels;      // src/clcontext.cpp:767
+    hipLaunchKernelGGL(k_reset, dim3((n + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, n);
+}
+void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
+{
+    hipLaunchKernelGGL(k_raygen, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
+}
+void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
+{
+    hipLaunchKernelGGL(k_postprocess, dim3((fr.localPixels + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, fr, p);
+}
+void launch_state_export(hipStream_t s, const State &st, float *out)
+{
+    hipLaunchKernelGGL(k_state_export, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, out);
+}
+void launch_state_import(hipStream_t s, const State &st, const float *in)
+{
+    hipLaunchKernelGGL(k_state_import, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, in);
+}
+
+} // namespace flxd

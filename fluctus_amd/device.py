@@ -1,0 +1,175 @@
+"""ctypes binding of libfluctus_hip.so (include/fluctus_hip.h).
+
+HipContext mirrors the reference's CLContext method for method (reference: src/clcontext.hpp:31-79):
+uploadSceneData -> upload_scene, createEnvMap -> upload_envmap, updateParams -> set_params,
+enqueueWf*Kernel -> wf_*, enqueueClearWfQueues -> clear_queues, enqueueGetCounters -> get_counters,
+finishQueue -> finish, updatePixelIndex/resetPixelIndex -> pixel_index_update/reset.
+There is NO CPU fallback: without the library or without a GPU every call raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+# every symbol include/fluctus_hip.h declares (checked by tests/test_abi.py against the header)
+SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "flx_upload_envmap", "flx_set_params",
+           "flx_wf_reset", "flx_wf_raygen", "flx_wf_extend", "flx_wf_shadow", "flx_wf_logic", "flx_wf_materials",
+           "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
+           "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
+           "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
+           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
+           "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option"]
+
+KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libfluctus_hip.so")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing -- the HIP extension is required (no fallback); run __graft_entry__.build()")
+        L = C.CDLL(path)
+        for s in SYMBOLS:
+            getattr(L, s)              # raises AttributeError if the library does not export it
+        L.flx_last_error.restype = C.c_char_p
+        L.flx_last_error.argtypes = [C.c_void_p]
+        L.flx_num_tasks.restype = C.c_uint32
+        L.flx_local_pixels.restype = C.c_uint32
+        L.flx_stream.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class HipContext:
+    name = "mi355x"
+
+    def __init__(self, num_tasks, device_index=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.num_tasks = int(num_tasks)
+        rc = self.L.flx_create(int(device_index), C.c_uint32(num_tasks), C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("flx_create failed: " + self.L.flx_last_error(None).decode())
+        self.params = None
+        self._cnt = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libfluctus_hip: " + self.L.flx_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.flx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, d):
+        self._chk(self.L.flx_upload_scene(self.h, _p(d.tris), C.c_size_t(d.tris.size), _p(d.indices), C.c_size_t(d.indices.size),
+                                          _p(d.nodes), C.c_size_t(d.nodes.size), _p(d.materials), C.c_size_t(d.materials.size),
+                                          _p(d.texdesc), C.c_size_t(d.texdesc.size), _p(d.texdata), C.c_size_t(d.texdata.size)))
+
+    def upload_envmap(self, e):
+        self._chk(self.L.flx_upload_envmap(self.h, _p(e.rgb), e.w, e.h, _p(e.prob), _p(e.alias), _p(e.pdf)))
+
+    def set_params(self, p):
+        self.params = p.copy()
+        self._chk(self.L.flx_set_params(self.h, _p(np.ascontiguousarray(self.params).reshape(1))))
+
+    def set_partition(self, rank, nranks):
+        self._chk(self.L.flx_set_partition(self.h, C.c_uint32(rank), C.c_uint32(nranks)))
+
+    def local_pixels(self):
+        return int(self.L.flx_local_pixels(self.h))
+
+    def wf_reset(self): self._chk(self.L.flx_wf_reset(self.h))
+    def wf_raygen(self): self._chk(self.L.flx_wf_raygen(self.h))
+    def wf_extend(self): self._chk(self.L.flx_wf_extend(self.h))
+    def wf_shadow(self): self._chk(self.L.flx_wf_shadow(self.h))
+    def wf_logic(self, first=False): self._chk(self.L.flx_wf_logic(self.h, int(bool(first))))
+    def wf_materials(self): self._chk(self.L.flx_wf_materials(self.h))
+    def postprocess(self): self._chk(self.L.flx_postprocess(self.h))
+    def clear_queues(self): self._chk(self.L.flx_clear_queues(self.h))
+
+    def get_counters(self):
+        """Asynchronous: the returned array is filled by the next finish()."""
+        out = np.zeros(8, np.uint32)
+        self._cnt.append(out)           # keep alive until finish
+        self._chk(self.L.flx_get_counters_async(self.h, _p(out)))
+        return out
+
+    def finish(self):
+        self._chk(self.L.flx_finish(self.h))
+        self._cnt.clear()
+
+    def set_counters(self, c):
+        c = np.ascontiguousarray(c, np.uint32)
+        self._chk(self.L.flx_set_counters(self.h, _p(c)))
+
+    def pixel_index_update(self, npix, nnew): self._chk(self.L.flx_pixel_index_update(self.h, C.c_uint32(npix), C.c_uint32(nnew)))
+    def pixel_index_reset(self): self._chk(self.L.flx_pixel_index_reset(self.h))
+
+    def read_pixels(self, which=0):
+        out = np.zeros((self.local_pixels(), 4), np.float32)
+        self._chk(self.L.flx_read_pixels(self.h, which, _p(out)))
+        return out
+
+    def copy_pixels_to_device(self, ptr):
+        self._chk(self.L.flx_copy_pixels_to_device(self.h, C.c_void_p(ptr)))
+
+    def state_export(self):
+        out = np.zeros((64, self.num_tasks), np.float32)
+        self._chk(self.L.flx_state_export(self.h, _p(out)))
+        return out
+
+    def state_import(self, st):
+        st = np.ascontiguousarray(st, np.float32)
+        assert st.shape == (64, self.num_tasks)
+        self._chk(self.L.flx_state_import(self.h, _p(st)))
+
+    def queue_read(self, q):
+        out = np.zeros(self.num_tasks, np.uint32)
+        self._chk(self.L.flx_queue_read(self.h, q, _p(out)))
+        return out
+
+    def queue_write(self, q, arr):
+        arr = np.ascontiguousarray(arr, np.uint32)
+        self._chk(self.L.flx_queue_write(self.h, q, _p(arr), C.c_uint32(arr.size)))
+
+    # measurement
+    def profile_enable(self, on=True): self._chk(self.L.flx_profile_enable(self.h, int(on)))
+    def profile_reset(self): self._chk(self.L.flx_profile_reset(self.h))
+
+    def profile_get(self):
+        out = {}
+        for name, k in KERNELS.items():
+            ms, n = C.c_double(), C.c_uint64()
+            self._chk(self.L.flx_profile_get(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def trace_stats_enable(self, on=True): self._chk(self.L.flx_trace_stats_enable(self.h, int(on)))
+    def reset_stats(self): self._chk(self.L.flx_trace_stats_reset(self.h))
+
+    def stats(self):
+        out = np.zeros(7, np.uint64)
+        self._chk(self.L.flx_trace_stats_get(self.h, _p(out)))
+        return dict(ext_rays=int(out[0]), ext_inner=int(out[1]), ext_tri=int(out[2]), ext_hits=int(out[3]),
+                    shadow_inner=int(out[4]), shadow_tri=int(out[5]), shadow_rays=int(out[6]))
+
+    def set_option(self, name, value): self._chk(self.L.flx_set_option(self.h, name.encode(), int(value)))

@@ -1,0 +1,123 @@
+/*
+ * fluctus_hip.h -- C ABI of libfluctus_hip.so, the MI355X (gfx950) implementation of the
+ * wavefront path-tracing hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one method of the reference's device
+ * context `class CLContext` (reference: src/clcontext.hpp:26-211, src/clcontext.cpp), the only
+ * object `Tracer` talks to for device work.  Plain pointers and sizes; no C++ or torch types.
+ * All functions return 0 on success and non-zero on failure (message: flx_last_error()); nothing
+ * throws or exits across the boundary (reference behaviour: clt::check() aborts,
+ * src/clcontext.cpp:931-936).
+ *
+ * Threading/ordering (same contract as the reference's single in-order cl::CommandQueue,
+ * src/clcontext.cpp:25-29): one host thread per context; every flx_wf_*, flx_clear_queues,
+ * flx_get_counters_async, flx_set_params, flx_pixel_index_* call is ASYNCHRONOUS and executes in
+ * issue order on the context's HIP stream; flx_finish() is the only synchronisation point
+ * (uploads and the read-back helpers are blocking).  Inputs are copied; the caller keeps ownership.
+ *
+ * Wire formats: include/fluctus_wire.h.
+ */
+#ifndef FLUCTUS_HIP_H
+#define FLUCTUS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "fluctus_wire.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct flx_ctx flx_ctx;
+
+/* CLContext::CLContext + setup (src/clcontext.cpp:18-69): pick HIP device `device`, create the
+ * stream, allocate path state for `num_tasks` paths (Settings wfBufferSize, src/settings.cpp:20)
+ * and the 8 index queues + counters (src/clcontext.cpp:116-141). */
+int flx_create(int device, uint32_t num_tasks, flx_ctx **out);
+int flx_destroy(flx_ctx *ctx);
+/* last error text of this context (or of flx_create when ctx == NULL) */
+const char *flx_last_error(flx_ctx *ctx);
+
+/* CLContext::uploadSceneData + packTextures (src/clcontext.cpp:522-611).  Takes the reference's
+ * wire arrays (160-B triangles, u32 index list, 48-B nodes, 80-B materials, 12-B texture
+ * descriptors + RGBA8 blob) and re-lays them out for CDNA4 on the device. */
+int flx_upload_scene(flx_ctx *ctx, const void *tris, size_t ntris, const uint32_t *indices, size_t nidx,
+                     const void *nodes, size_t nnodes, const void *materials, size_t nmat,
+                     const void *texdesc, size_t ntex, const uint8_t *texdata, size_t texbytes);
+
+/* CLContext::createEnvMap (src/clcontext.cpp:467-511): RGB float image + alias/prob/pdf tables. */
+int flx_upload_envmap(flx_ctx *ctx, const float *rgb, int w, int h, const float *prob, const int *alias, const float *pdf);
+
+/* CLContext::updateParams (src/clcontext.cpp:703-707), 240-byte RenderParams.  A change of
+ * width*height re-allocates the framebuffers (CLContext::setupPixelStorage/resizeBuffers). */
+int flx_set_params(flx_ctx *ctx, const void *render_params_240);
+
+/* enqueueWfResetKernel / RaygenKernel / ExtRayKernel / ShadowRayKernel / LogicKernel /
+ * MaterialKernels (src/clcontext.cpp:765-848).  Kernels: src/wf_reset.cl, wf_raygen.cl,
+ * wf_extrays.cl, wf_shadowrays.cl, wf_logic.cl, wf_mat_*.cl. */
+int flx_wf_reset(flx_ctx *ctx);
+int flx_wf_raygen(flx_ctx *ctx);
+int flx_wf_extend(flx_ctx *ctx);
+int flx_wf_shadow(flx_ctx *ctx);
+int flx_wf_logic(flx_ctx *ctx, int first_iteration);
+int flx_wf_materials(flx_ctx *ctx);           /* dispatches on params.wfSeparateQueues */
+
+/* enqueueClearWfQueues (src/clcontext.cpp:877-883) */
+int flx_clear_queues(flx_ctx *ctx);
+/* enqueueGetCounters (src/clcontext.cpp:668-671): asynchronous 32-byte read; *out32 (a
+ * flx_queue_counters) is valid only after the next flx_finish(). */
+int flx_get_counters_async(flx_ctx *ctx, void *out32);
+/* finishQueue (src/clcontext.cpp:885-889) */
+int flx_finish(flx_ctx *ctx);
+/* updatePixelIndex / resetPixelIndex (src/clcontext.cpp:891-901) */
+int flx_pixel_index_update(flx_ctx *ctx, uint32_t num_pixels, uint32_t num_new_paths);
+int flx_pixel_index_reset(flx_ctx *ctx);
+/* getNumTasks (src/clcontext.cpp:903-906) */
+uint32_t flx_num_tasks(flx_ctx *ctx);
+
+/* enqueuePostprocessKernel (src/clcontext.cpp:750-763; kernel src/mk_postprocess.cl) -- headless:
+ * the preview buffer is a plain device buffer, no GL interop. */
+int flx_postprocess(flx_ctx *ctx);
+/* saveImage's read-back half (src/clcontext.cpp:386-465): which = 0 raw accumulation (rgb sum,
+ * sample count), 1 = post-processed preview.  Blocking; out = float4 per (local) pixel. */
+int flx_read_pixels(flx_ctx *ctx, int which, float *out_rgba);
+
+/* ---- multi-GPU (no counterpart in the reference: one cl::CommandQueue, one device).
+ * Rank r of R owns global pixels p*R + r; its framebuffer holds ceil((w*h - r)/R) local pixels. */
+int flx_set_partition(flx_ctx *ctx, uint32_t rank, uint32_t nranks);
+uint32_t flx_local_pixels(flx_ctx *ctx);
+/* device-to-device copy of the raw accumulation buffer (local pixels, float4) into a caller-owned
+ * device buffer (e.g. a torch tensor handed to an RCCL gather); asynchronous on the context stream */
+int flx_copy_pixels_to_device(flx_ctx *ctx, void *dst_device_ptr);
+/* the context's hipStream_t, for callers that order their own work after ours */
+void *flx_stream(flx_ctx *ctx);
+
+/* ---- measurement.  Per-kernel HIP-event timing on the context's stream (the reference attaches
+ * cl::Events to the two trace kernels, src/clcontext.cpp:673-701,780,786).  kernel ids: */
+enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FLX_K_LOGIC = 4, FLX_K_MATERIALS = 5,
+       FLX_K_POSTPROCESS = 6, FLX_K_COUNT = 7 };
+int flx_profile_enable(flx_ctx *ctx, int on);
+/* after flx_finish(): accumulated milliseconds and launch count since the last reset */
+int flx_profile_get(flx_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+int flx_profile_reset(flx_ctx *ctx);
+/* traversal work counters (algorithmic-bytes model): when enabled the trace kernels
+ * accumulate {ext rays, ext inner-node visits, ext triangle tests, ext hits, shadow inner,
+ * shadow triangle tests, shadow rays}.  Counting launches are not used inside timed regions. */
+int flx_trace_stats_enable(flx_ctx *ctx, int on);
+int flx_trace_stats_get(flx_ctx *ctx, uint64_t *out7);
+int flx_trace_stats_reset(flx_ctx *ctx);
+
+/* ---- test hooks: path state in the reference's GPUTaskState SoA layout (64 columns x num_tasks
+ * words, src/geom.h:199-236), queues and counters.  Blocking. */
+int flx_state_export(flx_ctx *ctx, float *out_64xN);
+int flx_state_import(flx_ctx *ctx, const float *in_64xN);
+int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
+int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);
+int flx_set_counters(flx_ctx *ctx, const void *in32);
+/* tuning knobs (kernel variants); see DESIGN.md.  Unknown names fail. */
+int flx_set_option(flx_ctx *ctx, const char *name, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUCTUS_HIP_H */

@@ -46,10 +46,18 @@ FLX_HD float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 /* ---------------------------------------------------------------- scalars */
 
-FLX_HD float fminf_(float a, float b) { return a < b ? a : b; }
-FLX_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
+/* IEEE-754 minNum/maxNum (a NaN operand yields the other one) = OpenCL fmin/fmax = one
+ * v_min_f32 / v_max_f32 on the device.  The two spellings agree except for the sign of a zero
+ * result of min(-0,+0), which no comparison in the path can observe. */
+#if defined(__HIP_DEVICE_COMPILE__)
+FLX_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }
+FLX_HD float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+FLX_HD float fminf_(float a, float b) { return a < b ? a : (b != b ? a : b); }
+FLX_HD float fmaxf_(float a, float b) { return a > b ? a : (b != b ? a : b); }
+#endif
 FLX_HD float clampf(float v, float lo, float hi) { return fminf_(fmaxf_(v, lo), hi); }
-FLX_HD float absf(float a) { return u2f(f2u(a) & 0x7fffffffu); }
+FLX_HD float absf(float a) { return __builtin_fabsf(a); }
 
 /* sin and cos of x, |x| < 8192, Cody-Waite reduction to [-pi/4, pi/4]. */
 FLX_HD void sincosf_(float x, float *s, float *c)
