@@ -17,6 +17,7 @@ void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, co
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
 void launch_state_export(hipStream_t, const State &, float *);
 void launch_state_import(hipStream_t, const State &, const float *);
+void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t);
 }
 
 using namespace flxd;
@@ -43,6 +44,7 @@ struct flx_ctx {
     // trace aux
     uint32_t *spill = nullptr;
     unsigned long long *stats = nullptr;   // device, 7 counters
+    unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
     bool statsOn = false;
     int xcdRemap = 1;
     // owned device allocations
@@ -141,6 +143,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)32 * blocks * 256)) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->stats, 8)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->stats, 0, 64, c->stream);
+    if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream);
     c->fr.rank = 0; c->fr.nranks = 1; c->fr.localPixels = 0;
@@ -371,6 +375,22 @@ int flx_pixel_index_reset(flx_ctx *c)
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = 0;
     HIPCHK(c, hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream));
+    return 0;
+}
+
+int flx_end_iteration_async(flx_ctx *c)
+{
+    READY(c);
+    launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels);
+    LAUNCHED(c);
+    return 0;
+}
+int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out8, c->totals, 64, hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIPCHK(c, hipMemsetAsync(c->totals, 0, 64, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

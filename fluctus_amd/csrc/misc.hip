@@ -160,6 +160,21 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const flo
     st.firstDiffuse[gid] = __float_as_uint(R(FLX_COL_FIRST_DIFFUSE));
 }
 
+__global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels)
+{
+    const uint32_t i = threadIdx.x;
+    if (i < 8u) {
+        const uint32_t v = counters[i];
+        totals[i] += v;
+        if (i == FLX_Q_RAYGEN) *cursor = (uint32_t)(((unsigned long long)*cursor + v) % localPixels);
+        counters[i] = 0u;
+    }
+}
+void launch_end_iteration(hipStream_t s, uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels)
+{
+    hipLaunchKernelGGL(k_end_iteration, dim3(1), dim3(64), 0, s, counters, totals, cursor, localPixels);
+}
+
 void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
 {
     uint32_t n = st.numTasks > fr.localPixels ? st.numTasks : fr.localPixels;      // src/clcontext.cpp:767

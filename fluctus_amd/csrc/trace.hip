@@ -205,7 +205,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_extend(State st, Queues qs, Sce
     }
     st.rec[S_DIR][gid] = mk4u(dir, __float_as_uint(d4.w) + 1u);          // pathLen += 1
     st.rec[S_HITP][gid] = mk4(P, t);
-    st.rec[S_HITN][gid] = mk4u(N, flags);
+    // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
+    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(&st.rec[S_HITN][gid])[3]) & 2u;
+    st.rec[S_HITN][gid] = mk4u(N, flags | keep);
     st.rec[S_HITUV][gid] = make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId));
 
     if (STATS) {

@@ -17,7 +17,7 @@ _lib = None
 SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "flx_upload_envmap", "flx_set_params",
            "flx_wf_reset", "flx_wf_raygen", "flx_wf_extend", "flx_wf_shadow", "flx_wf_logic", "flx_wf_materials",
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
-           "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
+           "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option"]
@@ -123,6 +123,13 @@ class HipContext:
 
     def pixel_index_update(self, npix, nnew): self._chk(self.L.flx_pixel_index_update(self.h, C.c_uint32(npix), C.c_uint32(nnew)))
     def pixel_index_reset(self): self._chk(self.L.flx_pixel_index_reset(self.h))
+
+    def end_iteration_async(self): self._chk(self.L.flx_end_iteration_async(self.h))
+
+    def counter_totals(self, reset=False):
+        out = np.zeros(8, np.uint64)
+        self._chk(self.L.flx_counter_totals(self.h, _p(out), int(reset)))
+        return out
 
     def read_pixels(self, which=0):
         out = np.zeros((self.local_pixels(), 4), np.float32)

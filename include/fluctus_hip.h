@@ -72,6 +72,14 @@ int flx_finish(flx_ctx *ctx);
 /* updatePixelIndex / resetPixelIndex (src/clcontext.cpp:891-901) */
 int flx_pixel_index_update(flx_ctx *ctx, uint32_t num_pixels, uint32_t num_new_paths);
 int flx_pixel_index_reset(flx_ctx *ctx);
+/* Device-side end of a benchmark-style iteration (no counterpart in the reference, which needs a
+ * host round trip per iteration to move the cursor, src/tracer.cpp:456-462): in stream order,
+ * (1) add the 8 queue counters to 64-bit running totals, (2) cursor = (cursor + raygenQueue) %
+ * local pixels -- the value updatePixelIndex would write -- and (3) zero the counters
+ * (enqueueClearWfQueues).  Lets a caller run K iterations with a single flx_finish(). */
+int flx_end_iteration_async(flx_ctx *ctx);
+/* running totals accumulated by flx_end_iteration_async (8 x u64, flx_queue_counters order); blocking */
+int flx_counter_totals(flx_ctx *ctx, uint64_t *out8, int reset);
 /* getNumTasks (src/clcontext.cpp:903-906) */
 uint32_t flx_num_tasks(flx_ctx *ctx);
 

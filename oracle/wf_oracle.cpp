@@ -850,8 +850,9 @@ void k_raygen(Ctx &c)
     uint32_t qlen = c.counters.raygenQueue;
     uint32_t numPixelsGlobal = p.width * p.height;
     uint32_t numPixels = (numPixelsGlobal - c.rank + c.nranks - 1) / c.nranks;
-    for (uint32_t gd = 0; gd < c.numTasks; gd++) {
-        if (gd >= qlen) break;
+    const uint32_t extBase = c.counters.extensionQueue;
+#pragma omp parallel for schedule(static) num_threads(c.threads)
+    for (int64_t gd = 0; gd < (int64_t)std::min(qlen, c.numTasks); gd++) {
         uint32_t gid = c.queues[FLX_Q_RAYGEN][gd];
         uint32_t seed = U(c, FLX_COL_SEED, gid);
         uint32_t localIdx = (c.currPixelIdx + gd) % numPixels;
@@ -878,8 +879,7 @@ void k_raygen(Ctx &c)
         rayDirection = normalize(fp - rayOrig);
         W3(c, FLX_COL_ORIG, gid, rayOrig);
         W3(c, FLX_COL_DIR, gid, rayDirection);
-        uint32_t extIdx = c.counters.extensionQueue++;
-        c.queues[FLX_Q_EXTENSION][extIdx] = gid;
+        c.queues[FLX_Q_EXTENSION][extBase + (uint32_t)gd] = gid;   /* slot = old counter value, gid order */
         U(c, FLX_COL_SEED, gid) = seed;
         W3(c, FLX_COL_EI, gid, mk3(0.0f));
         W3(c, FLX_COL_T, gid, mk3(1.0f));
@@ -898,6 +898,7 @@ void k_raygen(Ctx &c)
         W3(c, FLX_COL_LAST_BSDF, gid, mk3(0.0f));
         writeHit(c, gid, emptyHit(FLX_FLT_MAX));
     }
+    c.counters.extensionQueue = extBase + std::min(qlen, c.numTasks);
 }
 
 /* reference: wf_extrays.cl:5-36 */
@@ -942,22 +943,38 @@ void k_shadow(Ctx &c)
     c.statShadowRays += qlen; c.stat[4] += sInner; c.stat[5] += sTri;
 }
 
+/* Queue appends.  Work-items run in ascending gid; with threads > 1 the range is cut into
+ * contiguous chunks, each chunk appends to private lists, and the lists are concatenated in chunk
+ * order afterwards -- the result is the sequential (canonical) queue order for any thread count. */
+struct Appender {
+    std::vector<uint32_t> l[FLX_NUM_QUEUES];
+    void push(int q, uint32_t gid) { l[q].push_back(gid); }
+};
+void mergeAppenders(Ctx &c, std::vector<Appender> &apps)
+{
+    uint32_t *len[FLX_NUM_QUEUES] = {&c.counters.raygenQueue, &c.counters.extensionQueue, &c.counters.shadowQueue, &c.counters.diffuseQueue,
+                                     &c.counters.glossyQueue, &c.counters.ggxReflQueue, &c.counters.ggxRefrQueue, &c.counters.deltaQueue};
+    for (auto &a : apps)
+        for (int q = 0; q < FLX_NUM_QUEUES; q++)
+            for (uint32_t g : a.l[q]) c.queues[q][(*len[q])++] = g;
+}
+
 /* reference: wf_logic.cl:322-372 (addToMaterialQueueNaive; WF_SINGLE_MAT_QUEUE iff !wfSeparateQueues,
  * kernel_impl.hpp:49-67) */
-void addToMaterialQueue(Ctx &c, uint32_t gid, const flx_material &mat)
+void addToMaterialQueue(Ctx &c, Appender &app, uint32_t gid, const flx_material &mat)
 {
-    int q; uint32_t *len;
-    if (!c.params.wfSeparateQueues) { q = FLX_Q_DIFFUSE; len = &c.counters.diffuseQueue; }
+    int q;
+    if (!c.params.wfSeparateQueues) q = FLX_Q_DIFFUSE;
     else switch (mat.type) {
-        case FLX_BXDF_DIFFUSE:              q = FLX_Q_DIFFUSE;  len = &c.counters.diffuseQueue;  break;
-        case FLX_BXDF_GLOSSY:               q = FLX_Q_GLOSSY;   len = &c.counters.glossyQueue;   break;
-        case FLX_BXDF_GGX_ROUGH_REFLECTION: q = FLX_Q_GGX_REFL; len = &c.counters.ggxReflQueue;  break;
-        case FLX_BXDF_GGX_ROUGH_DIELECTRIC: q = FLX_Q_GGX_REFR; len = &c.counters.ggxRefrQueue;  break;
+        case FLX_BXDF_DIFFUSE:              q = FLX_Q_DIFFUSE;  break;
+        case FLX_BXDF_GLOSSY:               q = FLX_Q_GLOSSY;   break;
+        case FLX_BXDF_GGX_ROUGH_REFLECTION: q = FLX_Q_GGX_REFL; break;
+        case FLX_BXDF_GGX_ROUGH_DIELECTRIC: q = FLX_Q_GGX_REFR; break;
         case FLX_BXDF_IDEAL_REFLECTION:
-        case FLX_BXDF_IDEAL_DIELECTRIC:     q = FLX_Q_DELTA;    len = &c.counters.deltaQueue;    break;
+        case FLX_BXDF_IDEAL_DIELECTRIC:     q = FLX_Q_DELTA;    break;
         default: return;
     }
-    c.queues[q][(*len)++] = gid;
+    app.push(q, gid);
 }
 
 /* reference: wf_logic.cl:14-314 */
@@ -965,7 +982,14 @@ void k_logic(Ctx &c, int firstIteration)
 {
     const flx_render_params &p = c.params;
     uint32_t maxId = firstIteration ? std::min(p.width * p.height, c.numTasks) : c.numTasks;
-    for (uint32_t gid = 0; gid < maxId; gid++) {
+    const int nthr = c.threads;
+    std::vector<Appender> apps(nthr);
+    const uint32_t chunk = (maxId + nthr - 1) / nthr;
+#pragma omp parallel for schedule(static, 1) num_threads(nthr)
+    for (int tchunk = 0; tchunk < nthr; tchunk++) {
+    Appender &app = apps[tchunk];
+    const uint32_t g0 = (uint32_t)tchunk * chunk, g1 = std::min(maxId, g0 + chunk);
+    for (uint32_t gid = g0; gid < g1; gid++) {
         uint32_t seed = U(c, FLX_COL_SEED, gid);
         uint32_t len = U(c, FLX_COL_PATH_LEN, gid);
         Hit hit = readHit(c, gid);
@@ -1039,9 +1063,19 @@ void k_logic(Ctx &c, int firstIteration)
                 uint32_t pixIdx = U(c, FLX_COL_PIXEL_INDEX, gid);
                 f3 Ei = R3(c, FLX_COL_EI, gid);
                 float *px = &c.pixels[(size_t)pixIdx * 4];
-                px[0] += Ei.x; px[1] += Ei.y; px[2] += Ei.z; px[3] += 1.0f;
+                if (nthr == 1) { px[0] += Ei.x; px[1] += Ei.y; px[2] += Ei.z; px[3] += 1.0f; }
+                else {
+#pragma omp atomic
+                    px[0] += Ei.x;
+#pragma omp atomic
+                    px[1] += Ei.y;
+#pragma omp atomic
+                    px[2] += Ei.z;
+#pragma omp atomic
+                    px[3] += 1.0f;
+                }
             }
-            c.queues[FLX_Q_RAYGEN][c.counters.raygenQueue++] = gid;
+            app.push(FLX_Q_RAYGEN, gid);
             U(c, FLX_COL_SEED, gid) = seed;
             continue;
         }
@@ -1078,7 +1112,7 @@ void k_logic(Ctx &c, int firstIteration)
                 F(c, FLX_COL_LAST_COS_TH, gid) = cosTh;
                 F(c, FLX_COL_LAST_PICK_PROB, gid) = lightPickProb;
                 W3(c, FLX_COL_LAST_EMISSION, gid, envMapLi);
-                c.queues[FLX_Q_SHADOW][c.counters.shadowQueue++] = gid;
+                app.push(FLX_Q_SHADOW, gid);
             }
             if (useAreaLight) {                        /* :261-300 */
                 float lightPickProb = 1.0f - envMapProb;
@@ -1098,21 +1132,30 @@ void k_logic(Ctx &c, int firstIteration)
                     F(c, FLX_COL_LAST_COS_TH, gid) = cosTh;
                     F(c, FLX_COL_LAST_PICK_PROB, gid) = lightPickProb;
                     W3(c, FLX_COL_LAST_EMISSION, gid, V(p.areaLight.E));
-                    c.queues[FLX_Q_SHADOW][c.counters.shadowQueue++] = gid;
+                    app.push(FLX_Q_SHADOW, gid);
                 } else {
                     U(c, FLX_COL_SHADOW_BLOCKED, gid) = 1;
                 }
             }
         }
         U(c, FLX_COL_SEED, gid) = seed;
-        addToMaterialQueue(c, gid, mat);
+        addToMaterialQueue(c, app, gid, mat);
     }
+    }
+    mergeAppenders(c, apps);
 }
 
 /* reference: wf_mat_diffuse.cl:7-67 (and its glossy/ggx_refl/ggx_refr/delta/all twins) */
 void k_material_queue(Ctx &c, int q, uint32_t qlen)
 {
-    for (uint32_t gd = 0; gd < qlen; gd++) {
+    const int nthr = c.threads;
+    std::vector<Appender> apps(nthr);
+    const uint32_t chunk = (qlen + nthr - 1) / nthr;
+#pragma omp parallel for schedule(static, 1) num_threads(nthr)
+    for (int tchunk = 0; tchunk < nthr; tchunk++) {
+    Appender &app = apps[tchunk];
+    const uint32_t g0 = (uint32_t)tchunk * chunk, g1 = std::min(qlen, g0 + chunk);
+    for (uint32_t gd = g0; gd < g1; gd++) {
         uint32_t gid = c.queues[q][gd];
         uint32_t seed = U(c, FLX_COL_SEED, gid);
         Hit hit = readHit(c, gid);
@@ -1140,8 +1183,10 @@ void k_material_queue(Ctx &c, int q, uint32_t qlen)
         F(c, FLX_COL_LAST_PDF_W, gid) = pdfW;
         U(c, FLX_COL_SEED, gid) = seed;
         U(c, FLX_COL_LAST_SPECULAR, gid) = FLX_BXDF_IS_SINGULAR(mat.type) ? 1u : 0u;
-        c.queues[FLX_Q_EXTENSION][c.counters.extensionQueue++] = gid;
+        app.push(FLX_Q_EXTENSION, gid);
     }
+    }
+    mergeAppenders(c, apps);
 }
 
 /* reference: clcontext.cpp:796-813 */
