@@ -60,13 +60,26 @@ def algorithmic_bytes(stats):
     return ext, sh
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs but grants 16 through cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(d, p, env, budget_s=12.0):
     """The oracle (CPU restatement of the reference kernels) on the host cores, bounded sample: the same
     scene / camera / parameters with 65 536 paths in flight, 16 warm-up iterations, then whole iterations
     until `budget_s` seconds have elapsed."""
     from fluctus_amd import driver
     from oracle.binding import OracleContext
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = 1 << 16
     c = OracleContext(n, threads=cores)
     c.upload_scene(d)
