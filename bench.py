@@ -206,12 +206,11 @@ def main():
         ctx.finish()
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        out = [torch.empty_like(tile) for _ in range(world)] if rank == 0 else None
-        dist.gather(tile, out, dst=0)
+        from fluctus_amd import multi
+        full = multi.gather_tiles(tile, args.width * args.height, rank, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            full = torch.stack(out, 1).reshape(-1, 4)[: args.width * args.height]   # de-interleave: pixel = p*R + r
             assert torch.isfinite(full).all() and lp > 0
 
     if rank == 0:

@@ -1,0 +1,99 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own kernels (oracle/_ref, this container only).
+
+  python scripts/make_golden.py
+
+Fixtures are data: input arrays (scene in wire format, parameters, states) and the outputs the
+reference kernels produced for them.  No reference source is stored.
+  teapot_wf.npz   config 1 of BASELINE.json (assets/teapot.ply, Lambertian, area light, 4 bounces, 128x128,
+                  16384 paths): per-iteration queue counters and the accumulated image after 24 iterations.
+  steps_*.npz     all-BSDF scene: path state / queues / counters after every kernel of two consecutive
+                  iterations (state k -> kernel -> state k+1 chains), for two flag sets.
+  raygen.npz      genRays outputs (seed stream, pixel index, ray origin/direction) for 4096 paths.
+"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import common  # noqa: E402
+from fluctus_amd import host, wire, driver  # noqa: E402
+from oracle.binding import RefContext  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def scene_arrays(d):
+    return dict(tris=d.tris.view(np.uint8).reshape(-1), nodes=d.nodes.view(np.uint8).reshape(-1), indices=d.indices,
+                materials=d.materials.view(np.uint8).reshape(-1), texdesc=d.texdesc.view(np.uint8).reshape(-1), texdata=d.texdata)
+
+
+def snapshot(c):
+    cnt = c.get_counters().copy()
+    return dict(state=c.state_export(), counters=cnt, queues=np.stack([c.queue_read(q) for q in range(8)]))
+
+
+def teapot():
+    d = host.load_scene("/root/reference/assets/teapot.ply")
+    host.build_bvh(d, "sbvh")
+    w = h = 128
+    n = w * h
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    p["maxBounces"] = 4
+    c = RefContext(n)
+    c.upload_scene(d); c.set_params(p); driver.reset_renderer(c)
+    cnts = np.stack([driver.benchmark_iteration(c, w * h) for _ in range(24)])
+    np.savez_compressed(os.path.join(OUT, "teapot_wf.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8),
+                        counters=cnts, pixels=c.read_pixels(0), **scene_arrays(d))
+    print("teapot_wf.npz", cnts[-1])
+
+
+def steps(tag, **flags):
+    d = common.mixed_material_scene()
+    w, h, n = 48, 32, 1024
+    p = common.scene_params(d, w, h, maxBounces=5, envMapStrength=1.5, **flags)
+    e = host.synthetic_sky(64, 32)
+    c = RefContext(n)
+    c.upload_scene(d); c.upload_envmap(e); c.set_params(p); driver.reset_renderer(c)
+    for _ in range(6):
+        driver.benchmark_iteration(c, w * h)
+    snaps, names = [snapshot(c)], ["start"]
+    for it in range(2):
+        for name, fn in (("logic", lambda: c.wf_logic(False)), ("raygen", c.wf_raygen), ("materials", c.wf_materials),
+                         ("extend", c.wf_extend), ("shadow", c.wf_shadow)):
+            fn()
+            snaps.append(snapshot(c)); names.append(name)
+        cnt = c.get_counters().copy()
+        c.clear_queues(); c.pixel_index_update(w * h, int(cnt[0]))
+        snaps.append(snapshot(c)); names.append("end")
+    np.savez_compressed(os.path.join(OUT, f"steps_{tag}.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8),
+                        names=np.array(names), states=np.stack([s["state"] for s in snaps]),
+                        counters=np.stack([s["counters"] for s in snaps]), queues=np.stack([s["queues"] for s in snaps]),
+                        env_rgb=e.rgb, env_prob=e.prob, env_alias=e.alias, env_pdf=e.pdf, env_wh=np.array([e.w, e.h]),
+                        pixel_cursor_start=np.array([0]), **scene_arrays(d))
+    print(f"steps_{tag}.npz", names)
+
+
+def raygen():
+    d = common.simple_scene()
+    w, h, n = 64, 64, 4096
+    p = common.scene_params(d, w, h)
+    p["camera"]["apertureSize"], p["camera"]["focalDist"] = 0.02, 2.5      # exercise the thin-lens branch
+    c = RefContext(n)
+    c.upload_scene(d); c.set_params(p)
+    c.pixel_index_reset(); c.wf_reset(); c.wf_raygen()
+    st = c.state_export()
+    np.savez_compressed(os.path.join(OUT, "raygen.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8), state=st,
+                        ext_queue=c.queue_read(1), counters=c.get_counters().copy())
+    print("raygen.npz")
+
+
+if __name__ == "__main__":
+    teapot()
+    steps("area_sep", useAreaLight=1, useEnvMap=0, wfSeparateQueues=1)
+    steps("env_area_single_rr", useAreaLight=1, useEnvMap=1, wfSeparateQueues=0, useRoulette=1)
+    raygen()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

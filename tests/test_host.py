@@ -1,0 +1,200 @@
+"""Host-side preparation (C++ libfluctus_host.so): loaders, BVH/SBVH builders, env-map tables, arithmetic contract."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+import common
+from fluctus_amd import host, wire
+from oracle import binding as ob
+
+REF = "/root/reference/assets"
+needs_ref_assets = pytest.mark.skipif(not os.path.isdir(REF), reason="reference assets only exist in the build container")
+
+
+def _check_bvh(d):
+    nodes, idx = d.nodes, d.indices
+    n = nodes.size
+    seen = np.zeros(d.tris.size, bool)
+    leaf_slots = 0
+    stack = [0]
+    visited = 0
+    tmin = np.minimum(np.minimum(_p(d, "v0"), _p(d, "v1")), _p(d, "v2"))
+    tmax = np.maximum(np.maximum(_p(d, "v0"), _p(d, "v1")), _p(d, "v2"))
+    while stack:
+        i = stack.pop()
+        visited += 1
+        nd = nodes[i]
+        bmin = np.array([nd["bmin"]["x"], nd["bmin"]["y"], nd["bmin"]["z"]])
+        bmax = np.array([nd["bmax"]["x"], nd["bmax"]["y"], nd["bmax"]["z"]])
+        if nd["nPrims"]:
+            s, c = int(nd["iStartOrRight"]), int(nd["nPrims"])
+            assert s + c <= idx.size
+            leaf_slots += c
+            for t in idx[s:s + c]:
+                seen[t] = True
+                # spatial splits clip references, so a leaf box only has to OVERLAP its triangles' boxes
+                assert (tmin[t] <= bmax + 1e-5).all() and (tmax[t] >= bmin - 1e-5).all()
+        else:
+            l, r = i + 1, int(nd["iStartOrRight"])
+            assert l < n and r < n and nodes[l]["parent"] == i and nodes[r]["parent"] == i
+            for ch in (l, r):
+                cm = np.array([nodes[ch]["bmin"]["x"], nodes[ch]["bmin"]["y"], nodes[ch]["bmin"]["z"]])
+                cM = np.array([nodes[ch]["bmax"]["x"], nodes[ch]["bmax"]["y"], nodes[ch]["bmax"]["z"]])
+                assert (cm >= bmin - 1e-5).all() and (cM <= bmax + 1e-5).all()
+            stack += [r, l]
+    assert visited == n and seen.all() and leaf_slots == idx.size
+
+
+def _p(d, v):
+    return np.stack([d.tris[v]["p"]["x"], d.tris[v]["p"]["y"], d.tris[v]["p"]["z"]], 1)
+
+
+@pytest.mark.parametrize("mode", ["sbvh", "sah", "binned"])
+def test_bvh_builders_produce_valid_trees(mode):
+    d = common.small_mesh_scene(n=8)
+    host.build_bvh(d, mode)
+    _check_bvh(d)
+    assert d.nodes[0]["parent"] == -1
+    assert d.bvh_metrics["depth"] <= 64
+    ext = np.array([d.nodes[0]["bmax"][k] - d.nodes[0]["bmin"][k] for k in "xyz"])
+    assert abs(d.world_radius - 0.5 * np.linalg.norm(ext)) < 1e-5      # reference: src/tracer.cpp:66-67
+
+
+def test_sbvh_creates_duplicates_only_with_spatial_splits():
+    d = host.generate_scene("conference", 20000, 43)
+    host.build_bvh(d, "sbvh")
+    assert d.indices.size == d.tris.size + d.bvh_metrics["duplicates"]
+    _check_bvh(d)
+
+
+def test_builders_agree_on_traversal_results():
+    """Closest hits do not depend on the tree: oracle traversal over SBVH vs SAH vs binned trees."""
+    from fluctus_amd import driver
+    res = []
+    for mode in ("sbvh", "sah", "binned"):
+        d = common.small_mesh_scene(n=8)
+        d.materials = np.array([common.default_material()], wire.MATERIAL)
+        d.texdesc = np.zeros(0, wire.TEXDESC); d.texdata = np.zeros(0, np.uint8)
+        host.build_bvh(d, mode)
+        p = common.scene_params(d, 64, 48)
+        p["worldRadius"] = 3.0
+        c = ob.OracleContext(64 * 48)
+        c.upload_scene(d); c.set_params(p)
+        c.pixel_index_reset(); c.wf_reset(); c.wf_raygen(); c.wf_extend()
+        st = c.state_export()
+        res.append((st[common.COL.HIT_T].copy(), st.view(np.uint32)[common.COL.HIT_I].copy()))
+    for t, i in res[1:]:
+        assert np.array_equal(t, res[0][0]) and np.array_equal(i, res[0][1])
+
+
+@needs_ref_assets
+def test_ply_loader_teapot():
+    d = host.load_scene(REF + "/teapot.ply")
+    assert d.tris.size == 3206 and d.materials.size == 1
+    m = d.materials[0]
+    assert m["type"] == wire.BXDF.DIFFUSE and abs(m["Kd"]["x"] - 0.64) < 1e-7 and m["Ni"] == np.float32(1.8) and m["Ns"] == 700.0
+    n = np.stack([d.tris["v0"]["n"]["x"], d.tris["v0"]["n"]["y"], d.tris["v0"]["n"]["z"]], 1)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-3)  # per-vertex normals were read
+    assert (d.tris["matId"] == 0).all()
+
+
+@needs_ref_assets
+def test_obj_mtl_loader_egyptcat():
+    d = host.load_scene(REF + "/egyptcat/egyptcat.obj")
+    faces = [l.split()[1:] for l in open(REF + "/egyptcat/egyptcat.obj") if l.startswith("f ")]
+    assert len(faces) == 16026                                     # 16 026 `f` lines
+    assert d.tris.size == sum(len(f) - 2 for f in faces)           # polygons are fan-triangulated (tinyobj triangulate=true)
+    assert d.materials.size == 4                                   # default + 3 from egyptcat.mtl
+    assert d.materials[1]["type"] == wire.BXDF.GLOSSY and d.materials[1]["Ns"] == 100000.0   # `shader glossy`
+    assert d.materials[2]["type"] == wire.BXDF.DIFFUSE
+    assert set(np.unique(d.tris["matId"])) <= {0, 1, 2, 3}
+
+
+def test_obj_loader_edge_cases(tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 0 0\nshader rough_reflection\nNs 50\nnewmtl b\nKd 0 1 0\nNi 1.5\nshader ideal_dielectric\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\n"
+                                    "f 1 2 3\nusemtl a\nf 1/1/1 2/2/1 3/3/1 4/1/1\nusemtl b\nf -4//1 -3//1 -2//1\nusemtl missing\nf 1 2 4\n")
+    d = host.load_scene(str(tmp_path / "m.obj"))
+    assert d.tris.size == 5                                        # 1 + quad fan (2) + 1 + 1
+    assert list(d.tris["matId"]) == [0, 1, 1, 2, 0]                # -1 -> default material 0, mtl index + 1 otherwise
+    assert d.materials[1]["type"] == wire.BXDF.GGX_ROUGH_REFLECTION and d.materials[2]["type"] == wire.BXDF.IDEAL_DIELECTRIC
+    assert d.tris[0]["v0"]["n"]["z"] == 1.0                        # flat normal generated when normals are missing
+    assert d.tris[1]["v1"]["t"]["x"] == 1.0                        # texcoords carried
+
+
+def test_envmap_alias_tables_are_a_valid_alias_method():
+    rng = np.random.RandomState(0)
+    w, h = 32, 16
+    img = rng.rand(h, w, 3).astype(np.float32) ** 4
+    img[3, 5] = 500.0
+    e = host.envmap_from_rgb(w, h, img)
+    n = w * h
+    assert abs(e.pdf.sum() / n - 1.0) < 1e-3                       # pdf is pre-multiplied by n (step-function pdf)
+    assert (e.prob >= 0).all() and (e.prob <= 1.0 + 1e-6).all() and (e.alias >= 0).all() and (e.alias < n).all()
+    # the alias method must reproduce pdf/n: P(i) = (prob[i] + sum_{j: alias[j]==i} (1 - prob[j])) / n
+    mass = e.prob.astype(np.float64).copy()
+    np.add.at(mass, e.alias, 1.0 - e.prob.astype(np.float64))
+    assert np.allclose(mass, e.pdf, rtol=2e-3, atol=2e-3)
+    assert e.pdf.reshape(h, w)[3, 5] == e.pdf.max()
+
+
+def test_envmap_all_black_falls_back_to_uniform():
+    e = host.envmap_from_rgb(8, 4, np.zeros((4, 8, 3), np.float32))
+    assert np.allclose(e.pdf, 1.0 / 32.0) and (e.prob <= 1.0).all()   # reference: src/envmap.cpp:62-63
+
+
+@needs_ref_assets
+@pytest.mark.ref
+def test_hdr_reader_matches_reference_rgbe():
+    """Our Radiance .hdr reader vs the reference's own src/rgbe/rgbe.cpp (compiled in oracle/_ref)."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    L = ob.ref_lib()
+    path = (REF + "/env_maps/night.hdr").encode()
+    w, h = C.c_int(), C.c_int()
+    assert L.ref_read_hdr(path, C.byref(w), C.byref(h), None) == 0
+    assert (w.value, h.value) == (512, 256)
+    ref = np.zeros(w.value * h.value * 3, np.float32)
+    assert L.ref_read_hdr(path, C.byref(w), C.byref(h), ref.ctypes.data_as(C.c_void_p)) == 0
+    e = host.load_envmap(REF + "/env_maps/night.hdr")
+    assert (e.w, e.h) == (512, 256) and np.array_equal(e.rgb, ref)
+    assert abs(float(e.pdf[0]) - 0.00115893) < 1e-7                # value recorded in SURVEY 8(c) from the reference's EnvironmentMap
+
+
+def test_procedural_scenes_are_deterministic_and_sized():
+    a = host.generate_scene("kitchen", 40000, 42)
+    b = host.generate_scene("kitchen", 40000, 42)
+    assert a.tris.tobytes() == b.tris.tobytes() and a.materials.tobytes() == b.materials.tobytes()
+    assert 0.7 * 40000 < a.tris.size < 1.3 * 40000
+    types = a.materials["type"][1:]
+    assert (types == wire.BXDF.DIFFUSE).sum() == 57 and (types == wire.BXDF.GLOSSY).sum() == 21    # Country-Kitchen.mtl mix
+    assert (types == wire.BXDF.IDEAL_REFLECTION).sum() == 8 and (types == wire.BXDF.GGX_ROUGH_REFLECTION).sum() == 6
+    assert (types == wire.BXDF.IDEAL_DIELECTRIC).sum() == 4 and a.texdesc.size == 17
+    c = host.generate_scene("conference", 30000, 43)
+    t = c.materials["type"][1:]
+    assert abs((t == wire.BXDF.GGX_ROUGH_REFLECTION).mean() - 0.5) < 1e-6
+
+
+def test_math_contract_accuracy():
+    """include/flx_math.h vs numpy (float64): the gap the oracle-vs-reference tolerance has to cover."""
+    L = ob.lib()
+    f = np.vectorize(lambda fn, a, b=0.0: L.orc_math(fn, float(a), float(b)))
+    x = np.linspace(-3.2, 6.4, 4001).astype(np.float32)
+    assert np.abs(f(0, x) - np.sin(x.astype(np.float64))).max() < 3e-7
+    assert np.abs(f(1, x) - np.cos(x.astype(np.float64))).max() < 3e-7
+    y = np.linspace(-1, 1, 2001).astype(np.float32)
+    assert np.abs(f(4, y) - np.arccos(y.astype(np.float64))).max() < 6e-7
+    a, b = np.random.RandomState(1).uniform(-2, 2, (2, 3000)).astype(np.float32)
+    assert np.abs(f(3, a, b) - np.arctan2(a.astype(np.float64), b.astype(np.float64))).max() < 6e-7
+    c = np.linspace(1e-3, 4, 3000).astype(np.float32)
+    for e in (2.2, 1.0 / 2.2):
+        ref = c.astype(np.float64) ** np.float64(np.float32(e))
+        assert (np.abs(f(5, c, e) - ref) / ref).max() < 2e-6
+    assert abs(L.orc_math(2, float(np.float32(np.pi / 6)), 0.0) - np.tan(np.float32(np.pi / 6))) < 2e-7
+    # hash RNG known answers (reference: src/random.cl:7-15, computed by hand from the definition)
+    def h(s):
+        s = ((s ^ 61) ^ (s >> 16)) & 0xffffffff; s = (s * 9) & 0xffffffff; s ^= s >> 4
+        s = (s * 0x27d4eb2d) & 0xffffffff; s ^= s >> 15
+        return s
+    for s in (0, 1, 61, 2**32 - 1, 123456789):
+        assert L.orc_hash(s) == h(s)

@@ -1,0 +1,127 @@
+"""The CPU oracle against the committed golden fixtures (tests/golden/*.npz), which hold outputs of the
+REFERENCE's own kernels (generated in the build container by scripts/make_golden.py from oracle/_ref).
+Runs everywhere (no /root/reference needed): this is what pins the oracle on the GPU box."""
+import os
+import numpy as np
+import pytest
+import common
+from common import COL
+from fluctus_amd import host, wire, driver
+from oracle.binding import OracleContext
+
+
+def _load_scene(z):
+    d = host.SceneData()
+    d.tris = z["tris"].view(wire.TRIANGLE).reshape(-1)
+    d.nodes = z["nodes"].view(wire.NODE).reshape(-1)
+    d.indices = z["indices"]
+    d.materials = z["materials"].view(wire.MATERIAL).reshape(-1)
+    d.texdesc = z["texdesc"].view(wire.TEXDESC).reshape(-1) if z["texdesc"].size else np.zeros(0, wire.TEXDESC)
+    d.texdata = z["texdata"]
+    return d
+
+
+def _fixture(name):
+    path = os.path.join(common.GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} missing")
+    return np.load(path)
+
+
+def test_raygen_golden():
+    """G1+G2: RNG stream (4 draws per primary ray), pixel assignment, thin-lens camera rays."""
+    z = _fixture("raygen.npz")
+    n = int(z["num_tasks"])
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    d = common.simple_scene()
+    c = OracleContext(n)
+    c.upload_scene(d); c.set_params(p)
+    c.pixel_index_reset(); c.wf_reset(); c.wf_raygen()
+    assert np.array_equal(c.get_counters(), z["counters"])
+    assert np.array_equal(c.queue_read(1), z["ext_queue"])
+    fails = common.state_diff(c.state_export(), z["state"], 2e-6, 1e-6)
+    assert not fails, "; ".join(fails)
+
+
+@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr"])
+def test_kernel_steps_golden(tag):
+    """G3/G4/G6: every kernel of two iterations, all six BSDFs, textures, env-map MIS: oracle output from the
+    reference's input state vs the reference's output state."""
+    z = _fixture(f"steps_{tag}.npz")
+    n = int(z["num_tasks"])
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    d = _load_scene(z)
+    w, h = int(z["env_wh"][0]), int(z["env_wh"][1])
+    e = host.EnvMap(w, h, z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])
+    c = OracleContext(n)
+    c.upload_scene(d); c.upload_envmap(e); c.set_params(p)
+    names = [str(s) for s in z["names"]]
+    npix = int(p["width"]) * int(p["height"])
+    # the fixture starts after 6 free-running reference iterations; replay the cursor from the counters
+    c.pixel_index_reset()
+    fn = {"logic": lambda: c.wf_logic(False), "raygen": c.wf_raygen, "materials": c.wf_materials, "extend": c.wf_extend, "shadow": c.wf_shadow}
+    for k in range(1, len(names)):
+        if names[k] == "end":
+            continue
+        prev = k - 1
+        c.state_import(z["states"][prev])
+        for q in range(8):
+            c.queue_write(q, z["queues"][prev][q])
+        c.set_counters(z["counters"][prev])
+        if names[k] == "raygen":
+            continue            # needs the reference's pixel cursor; covered by test_raygen_golden and the e2e fixture
+        fn[names[k]]()
+        assert np.array_equal(c.get_counters(), z["counters"][k]), (k, names[k])
+        for q in range(8):
+            m = int(z["counters"][k][q])
+            assert np.array_equal(c.queue_read(q)[:m], z["queues"][k][q][:m]), (names[k], q)
+        sa, sb = c.state_export(), z["states"][k]
+        mask = None
+        if names[k] == "materials":   # pdfW is uninitialised in the reference when the glossy sampler rejects (T == 0 there)
+            mask = ~((sa[COL.T] == 0) & (sa[COL.T + 1] == 0) & (sa[COL.T + 2] == 0))
+        rtol = 1e-3 if names[k] == "materials" else 1e-4
+        fails = common.state_diff(sa, sb, rtol, 1e-5, mask=mask)
+        assert not fails, f"step {k} {names[k]}: " + "; ".join(fails[:4])
+
+
+def test_teapot_end_to_end_golden():
+    """G7 / config 1: teapot.ply, 128x128, 4 bounces, area light, 24 free-running iterations."""
+    z = _fixture("teapot_wf.npz")
+    n = int(z["num_tasks"])
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    d = _load_scene(z)
+    w, h = int(p["width"]), int(p["height"])
+    c = OracleContext(n, threads=4)
+    c.upload_scene(d); c.set_params(p); driver.reset_renderer(c)
+    cnts = z["counters"]
+    for it in range(cnts.shape[0]):
+        cnt = driver.benchmark_iteration(c, w * h)
+        # free-running: ulp-level differences (libm vs flx_math) flip a few grazing rays per iteration (<= 1e-5 of rays
+        # per kernel; they accumulate over iterations)
+        assert np.all(np.abs(cnt.astype(np.int64) - cnts[it].astype(np.int64)) <= max(4, int(2e-3 * n))), (it, cnt, cnts[it])
+    px, ref = c.read_pixels(0), z["pixels"]
+    assert np.abs(px[:, 3] - ref[:, 3]).max() <= 3
+    m = (ref[:, 3] >= 1) & (px[:, 3] == ref[:, 3])
+    a, b = px[m, :3] / px[m, 3:], ref[m, :3] / ref[m, 3:]
+    close = np.isclose(a, b, rtol=1e-3, atol=1e-4).all(1)
+    # One flipped grazing ray changes when its path terminates, hence the order of the raygen queue and the pixel/seed pairing
+    # of every later regenerated path (src/wf_raygen.cl:25): after 24 free-running iterations ~5 % of the pixels hold different
+    # sample sets.  Per-kernel parity is pinned by test_kernel_steps_golden; here the check is statistical.
+    assert close.mean() > 0.9
+    assert abs(a.mean() - b.mean()) <= 5e-3 * b.mean()
+
+
+def test_thread_count_does_not_change_results():
+    """The OpenMP oracle must reproduce the sequential (canonical) order for any thread count."""
+    d = common.mixed_material_scene()
+    w, h, n = 48, 32, 2048
+    p = common.scene_params(d, w, h, maxBounces=5, useEnvMap=1, wfSeparateQueues=1)
+    e = host.synthetic_sky(32, 16)
+    outs = []
+    for thr in (1, 5):
+        c = OracleContext(n, threads=thr)
+        c.upload_scene(d); c.upload_envmap(e); c.set_params(p); driver.reset_renderer(c)
+        cn = [driver.benchmark_iteration(c, w * h) for _ in range(10)]
+        outs.append((np.stack(cn), c.state_export(), np.stack([c.queue_read(q) for q in range(8)])))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert not common.state_diff(outs[0][1], outs[1][1], 0.0, 0.0)
