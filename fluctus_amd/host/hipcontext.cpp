@@ -1,0 +1,132 @@
+// hipcontext.cpp -- see hipcontext.hpp.
+#include "hipcontext.hpp"
+#include <dlfcn.h>
+#include <stdexcept>
+#include <cstdio>
+#include <cmath>
+#include <fstream>
+
+namespace fluctus {
+
+struct HipContext::Api {
+#define FN(name) decltype(&::name) name = nullptr;
+    FN(flx_create) FN(flx_destroy) FN(flx_last_error) FN(flx_upload_scene) FN(flx_upload_envmap) FN(flx_set_params)
+    FN(flx_wf_reset) FN(flx_wf_raygen) FN(flx_wf_extend) FN(flx_wf_shadow) FN(flx_wf_logic) FN(flx_wf_materials)
+    FN(flx_clear_queues) FN(flx_get_counters_async) FN(flx_finish) FN(flx_pixel_index_update) FN(flx_pixel_index_reset)
+    FN(flx_num_tasks) FN(flx_postprocess) FN(flx_read_pixels) FN(flx_set_partition) FN(flx_local_pixels)
+#undef FN
+};
+
+static std::string defaultLibPath()
+{
+    Dl_info info;
+    if (dladdr((void *)&defaultLibPath, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.find_last_of('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/libfluctus_hip.so";
+    }
+    return "libfluctus_hip.so";
+}
+
+HipContext::HipContext(int device, uint32_t numTasks, const std::string &libPath)
+{
+    std::string path = libPath.empty() ? defaultLibPath() : libPath;
+    dl = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!dl) throw std::runtime_error(std::string("HipContext: cannot load ") + path + ": " + dlerror() + " (the HIP library is required; there is no CPU fallback)");
+    api = new Api();
+#define BIND(name) api->name = (decltype(api->name))dlsym(dl, #name); if (!api->name) throw std::runtime_error("HipContext: missing symbol " #name);
+    BIND(flx_create) BIND(flx_destroy) BIND(flx_last_error) BIND(flx_upload_scene) BIND(flx_upload_envmap) BIND(flx_set_params)
+    BIND(flx_wf_reset) BIND(flx_wf_raygen) BIND(flx_wf_extend) BIND(flx_wf_shadow) BIND(flx_wf_logic) BIND(flx_wf_materials)
+    BIND(flx_clear_queues) BIND(flx_get_counters_async) BIND(flx_finish) BIND(flx_pixel_index_update) BIND(flx_pixel_index_reset)
+    BIND(flx_num_tasks) BIND(flx_postprocess) BIND(flx_read_pixels) BIND(flx_set_partition) BIND(flx_local_pixels)
+#undef BIND
+    if (api->flx_create(device, numTasks, &ctx) != 0)
+        throw std::runtime_error(std::string("HipContext: ") + api->flx_last_error(nullptr));
+}
+
+HipContext::~HipContext()
+{
+    if (ctx && api) api->flx_destroy(ctx);
+    delete api;
+    if (dl) dlclose(dl);
+}
+
+// reference: CLContext::verify -> clt::check (src/clcontext.cpp:931-936); here an exception instead of exit()
+void HipContext::check(int rc, const char *what)
+{
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + api->flx_last_error(ctx));
+}
+
+void HipContext::uploadSceneData(BVH *bvh, Scene *scene)
+{
+    std::vector<flx_texdesc> descs; std::vector<uint8_t> blob;
+    scene->packTextures(descs, blob);
+    auto &tris = scene->getTriangles(); auto &mats = scene->getMaterials();
+    check(api->flx_upload_scene(ctx, tris.data(), tris.size(), bvh->m_indices.data(), bvh->m_indices.size(), bvh->m_nodes.data(), bvh->m_nodes.size(),
+                                mats.data(), mats.size(), descs.data(), descs.size(), blob.data(), blob.size()), "uploadSceneData");
+}
+void HipContext::createEnvMap(EnvironmentMap *m)
+{
+    check(api->flx_upload_envmap(ctx, m->getData(), m->getWidth(), m->getHeight(), m->getProbTable(), m->getAliasTable(), m->getPdfTable()), "createEnvMap");
+}
+void HipContext::updateParams(const RenderParams &p) { check(api->flx_set_params(ctx, &p), "updateParams"); }
+void HipContext::enqueueWfResetKernel(const RenderParams &) { check(api->flx_wf_reset(ctx), "wf_reset"); }
+void HipContext::enqueueWfRaygenKernel(const RenderParams &) { check(api->flx_wf_raygen(ctx), "wf_raygen"); }
+void HipContext::enqueueWfExtRayKernel(const RenderParams &) { check(api->flx_wf_extend(ctx), "wf_extension"); }
+void HipContext::enqueueWfShadowRayKernel(const RenderParams &) { check(api->flx_wf_shadow(ctx), "wf_shadow"); }
+void HipContext::enqueueWfLogicKernel(const RenderParams &, bool first) { check(api->flx_wf_logic(ctx, first ? 1 : 0), "wf_logic"); }
+void HipContext::enqueueWfMaterialKernels(const RenderParams &) { check(api->flx_wf_materials(ctx), "wf_materials"); }
+void HipContext::enqueueClearWfQueues() { check(api->flx_clear_queues(ctx), "clear queues"); }
+void HipContext::enqueueGetCounters(QueueCounters *cnt) { check(api->flx_get_counters_async(ctx, cnt), "get counters"); }
+void HipContext::enqueuePostprocessKernel(const RenderParams &) { check(api->flx_postprocess(ctx), "postprocess"); }
+void HipContext::finishQueue() { check(api->flx_finish(ctx), "finish"); }
+void HipContext::updatePixelIndex(uint32_t n, uint32_t nnew) { check(api->flx_pixel_index_update(ctx, n, nnew), "updatePixelIndex"); }
+void HipContext::resetPixelIndex() { check(api->flx_pixel_index_reset(ctx), "resetPixelIndex"); }
+uint32_t HipContext::getNumTasks() const { return api->flx_num_tasks(ctx); }
+void HipContext::setPartition(uint32_t r, uint32_t n) { check(api->flx_set_partition(ctx, r, n), "setPartition"); }
+uint32_t HipContext::localPixels() const { return api->flx_local_pixels(ctx); }
+
+void HipContext::readPixels(int which, std::vector<float> &rgba)
+{
+    rgba.resize((size_t)localPixels() * 4);
+    check(api->flx_read_pixels(ctx, which, rgba.data()), "read pixels");
+}
+
+void HipContext::saveImage(const std::string &filename, const RenderParams &p)
+{
+    const bool raw = filename.size() > 4 && filename.compare(filename.size() - 4, 4, ".pfm") == 0;
+    std::vector<float> px;
+    if (!raw) { enqueuePostprocessKernel(p); }
+    readPixels(raw ? 0 : 1, px);
+    const uint32_t w = p.width, h = p.height;
+    if ((size_t)w * h != px.size() / 4) throw std::runtime_error("saveImage: partitioned framebuffer; gather the tiles first");
+    std::ofstream out(filename, std::ios::binary);
+    if (raw) {
+        out << "PF\n" << w << " " << h << "\n-1.0\n";                 // little-endian, bottom row first = our row 0 (y up)
+        for (uint32_t i = 0; i < w * h; i++) {
+            float c = px[i * 4 + 3] > 0 ? px[i * 4 + 3] : 1.0f;
+            float rgb[3] = {px[i * 4] / c, px[i * 4 + 1] / c, px[i * 4 + 2] / c};
+            out.write((const char *)rgb, 12);
+        }
+    } else {
+        out << "P6\n" << w << " " << h << "\n255\n";
+        for (int y = (int)h - 1; y >= 0; y--)
+            for (uint32_t x = 0; x < w; x++) {
+                unsigned char c[3];
+                for (int k = 0; k < 3; k++) { float v = px[((size_t)y * w + x) * 4 + k]; v = v < 0 ? 0 : (v > 1 ? 1 : v); c[k] = (unsigned char)std::lround(v * 255.0f); }
+                out.write((const char *)c, 3);
+            }
+    }
+}
+
+void HipContext::updateRenderPerf(float deltaT)
+{
+    double scale = 1e6 * deltaT;
+    renderPerf.primary = statsAsync.primaryRays / scale;
+    renderPerf.extension = statsAsync.extensionRays / scale;
+    renderPerf.shadow = statsAsync.shadowRays / scale;
+    renderPerf.samples = statsAsync.samples / scale;
+    renderPerf.total = renderPerf.primary + renderPerf.extension + renderPerf.shadow;
+}
+
+} // namespace fluctus

@@ -111,3 +111,37 @@ int fh_envmap_get(void *e, float *rgb, float *prob, int *alias, float *pdf)
 }
 
 } // extern "C"
+
+// ---- headless Tracer (C++ render driver over HipContext / libfluctus_hip.so)
+#include "tracer.hpp"
+extern "C" {
+int fh_tracer_create(int width, int height, int device, uint32_t numTasks, void **out) { FH_TRY *out = new Tracer(width, height, device, numTasks); FH_CATCH }
+int fh_tracer_destroy(void *t) { delete (Tracer *)t; return 0; }
+int fh_tracer_init(void *t, int width, int height, const char *scene) { FH_TRY ((Tracer *)t)->init(width, height, scene); FH_CATCH }
+int fh_tracer_set_envmap(void *t, const char *hdr) { FH_TRY ((Tracer *)t)->setEnvMap(hdr); FH_CATCH }
+int fh_tracer_params(void *t, void *out240, const void *in240)
+{
+    FH_TRY
+    Tracer *tr = (Tracer *)t;
+    if (in240) { memcpy(&tr->getParams(), in240, 240); tr->paramsChanged(); }
+    if (out240) memcpy(out240, &tr->getParams(), 240);
+    FH_CATCH
+}
+int fh_tracer_update(void *t, void *counters32) { FH_TRY ((Tracer *)t)->update(); if (counters32) memcpy(counters32, &((Tracer *)t)->lastCounters(), 32); FH_CATCH }
+int fh_tracer_run_benchmark(void *t, double seconds, int iterations, char *csv, uint64_t cap)
+{
+    FH_TRY
+    std::string s = ((Tracer *)t)->runBenchmark(seconds, iterations);
+    if (csv && cap) { size_t n = s.size() < cap - 1 ? s.size() : cap - 1; memcpy(csv, s.data(), n); csv[n] = 0; }
+    FH_CATCH
+}
+int fh_tracer_read_pixels(void *t, int which, float *out, uint64_t capFloats)
+{
+    FH_TRY
+    std::vector<float> px; ((Tracer *)t)->getContext()->readPixels(which, px);
+    if (px.size() > capFloats) throw std::runtime_error("fh_tracer_read_pixels: buffer too small");
+    memcpy(out, px.data(), px.size() * 4);
+    FH_CATCH
+}
+int fh_tracer_save_image(void *t, const char *path) { FH_TRY ((Tracer *)t)->saveImage(path); FH_CATCH }
+}

@@ -1,0 +1,193 @@
+// tracer.cpp -- see tracer.hpp.
+#include "tracer.hpp"
+#include <chrono>
+#include <sstream>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <stdexcept>
+
+namespace fluctus {
+
+static flx_vec3 v3(float x, float y, float z, float w = 0.0f) { return flx_vec3{x, y, z, w}; }
+
+Tracer::Tracer(int width, int height, int device, uint32_t numTasks)
+{
+    std::memset(&params, 0, sizeof(params));
+    resetParams(width, height);
+    initCamera();
+    initPostProcessing();
+    initAreaLight();
+    scene.reset(new Scene());
+    clctx.reset(new HipContext(device, numTasks));
+}
+
+Tracer::~Tracer() { delete bvh; }
+
+// reference: src/tracer.cpp:38-52
+void Tracer::resetParams(int width, int height)
+{
+    params.width = (uint32_t)width; params.height = (uint32_t)height;
+    params.useEnvMap = 0; params.useAreaLight = 1; params.envMapStrength = 1.0f; params.maxBounces = 10;
+    params.sampleImpl = 1; params.sampleExpl = 1; params.useRoulette = 0; params.wfSeparateQueues = 0;
+}
+// reference: src/tracer.cpp:760-776
+void Tracer::initCamera()
+{
+    flx_camera &c = params.camera;
+    c.pos = v3(0.0f, 1.0f, 3.5f); c.right = v3(1.0f, 0.0f, 0.0f); c.up = v3(0.0f, 1.0f, 0.0f); c.dir = v3(0.0f, 0.0f, -1.0f);
+    c.fov = 60.0f; c.apertureSize = 0.0f; c.focalDist = 0.5f;
+    paramsUpdatePending = true;
+}
+// reference: src/tracer.cpp:778-786
+void Tracer::initPostProcessing() { params.exposure = 1.0f; params.tmOperator = 2; paramsUpdatePending = true; }
+// reference: src/tracer.cpp:788-797
+void Tracer::initAreaLight()
+{
+    flx_arealight &l = params.areaLight;
+    l.E = v3(200.0f, 200.0f, 200.0f); l.right = v3(0.0f, 0.0f, -1.0f); l.up = v3(0.0f, 1.0f, 0.0f);
+    l.N = v3(-1.0f, 0.0f, 0.0f, 0.0f); l.pos = v3(1.0f, 1.0f, 0.0f, 1.0f); l.size.x = 0.5f; l.size.y = 0.5f;
+    paramsUpdatePending = true;
+}
+
+static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// reference: src/tracer.cpp:574-590 -- cached hierarchy if present, else SBVH (always SplitMode::SAH -> SBVH) + export.
+// The cache key hashes the triangle positions instead of the file bytes (procedural scenes have no file).
+void Tracer::initHierarchy()
+{
+    delete bvh; bvh = new BVH();
+    auto &tris = scene->getTriangles();
+    params.n_tris = (uint32_t)tris.size();
+    std::string cache;
+    if (!hierarchyCacheDir.empty()) {
+        std::ostringstream ss; ss << hierarchyCacheDir << "/hierarchy_" << fnv1a(tris.data(), tris.size() * sizeof(flx_triangle)) << ".bin";
+        cache = ss.str();
+        if (bvh->importFrom(cache)) return;
+    }
+    bvh->build(&tris, BVH::Mode::SBVH);
+    if (!cache.empty()) bvh->exportTo(cache);
+}
+
+// reference: src/tracer.cpp:55-80
+void Tracer::init(int width, int height, const std::string &sceneFile)
+{
+    resetParams(width, height);
+    scene.reset(new Scene());
+    sceneName = sceneFile;
+    if (sceneFile.compare(0, 5, "proc:") == 0) {
+        std::string kind; uint32_t tris = 100000, seed = 42;
+        std::istringstream ss(sceneFile.substr(5)); std::string tok;
+        if (std::getline(ss, tok, ':')) kind = tok;
+        if (std::getline(ss, tok, ':')) tris = (uint32_t)std::stoul(tok);
+        if (std::getline(ss, tok, ':')) seed = (uint32_t)std::stoul(tok);
+        scene->generate(kind, tris, seed);
+    } else scene->loadModel(sceneFile);
+    initHierarchy();
+    params.worldRadius = bvh->worldRadius();                 // :66-67
+    clctx->uploadSceneData(bvh, scene.get());
+    delete bvh; bvh = nullptr;                               // :72-73 data lives on the GPU now
+    paramsUpdatePending = true;
+    iteration = 0;
+}
+
+void Tracer::setEnvMap(const std::string &hdrFile)
+{
+    envMap.reset(new EnvironmentMap(hdrFile));
+    clctx->createEnvMap(envMap.get());
+    params.useEnvMap = 1;
+    paramsUpdatePending = true;
+}
+
+// reference: src/tracer.cpp:189-358, wavefront branch
+void Tracer::update()
+{
+    if (paramsUpdatePending) { clctx->updateParams(params); paramsUpdatePending = false; iteration = 0; }
+    QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
+    uint32_t maxBounces = params.maxBounces;
+    int N = 1;
+    if (iteration == 0) {
+        params.maxBounces = std::min((uint32_t)2, maxBounces);           // 2-bounce preview
+        clctx->updateParams(params);
+        N = 3;
+        clctx->resetPixelIndex();
+        clctx->enqueueWfResetKernel(params);
+        clctx->enqueueWfRaygenKernel(params);
+        clctx->enqueueWfExtRayKernel(params);
+        clctx->enqueueClearWfQueues();
+    }
+    for (int i = 0; i < N; i++) {
+        clctx->enqueueWfLogicKernel(params, iteration == 0);
+        clctx->enqueueWfRaygenKernel(params);
+        clctx->enqueueWfMaterialKernels(params);
+        clctx->enqueueGetCounters(&cnt);
+        clctx->enqueueWfExtRayKernel(params);
+        clctx->enqueueWfShadowRayKernel(params);
+        clctx->enqueueClearWfQueues();
+    }
+    if (iteration == 0) { params.maxBounces = maxBounces; clctx->updateParams(params); }
+    clctx->enqueuePostprocessKernel(params);
+    clctx->finishQueue();
+    clctx->updatePixelIndex(clctx->localPixels(), cnt.raygenQueue);
+    clctx->statsAsync.extensionRays += cnt.extensionQueue;               // :336-339
+    clctx->statsAsync.shadowRays += cnt.shadowQueue;
+    clctx->statsAsync.primaryRays += cnt.raygenQueue;
+    clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
+    lastCnt = cnt;
+    iteration++;
+}
+
+// reference: src/tracer.cpp:362-528, wavefront body
+std::string Tracer::runBenchmark(double seconds, int iterations)
+{
+    using clk = std::chrono::steady_clock;
+    auto now = [] { return std::chrono::duration<double>(clk::now().time_since_epoch()).count(); };
+    std::ostringstream csv;
+    csv << "scene;time;primary;extension;shadow;total;samples\n";
+    // resetRenderer (:372-382)
+    iteration = 0;
+    clctx->updateParams(params); paramsUpdatePending = false;
+    clctx->resetPixelIndex();
+    clctx->enqueueWfResetKernel(params);
+    clctx->enqueueClearWfQueues();
+    clctx->finishQueue();
+    clctx->resetStats();
+    double startT = now(), lastLog = startT, currT = startT;
+    int it = 0;
+    auto log = [&](double t) {
+        RenderStats s = clctx->getStats(); clctx->resetStats();
+        double dt = t - lastLog, sc = 1e6 * dt; lastLog = t;
+        csv << sceneName << ";" << (t - startT) << ";" << s.primaryRays / sc << ";" << s.extensionRays / sc << ";" << s.shadowRays / sc << ";"
+            << (s.primaryRays + s.extensionRays + s.shadowRays) / sc << ";" << s.samples / sc << "\n";
+    };
+    while (iterations > 0 ? it < iterations : currT - startT < seconds) {
+        QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
+        clctx->enqueueWfLogicKernel(params, false);
+        clctx->enqueueWfRaygenKernel(params);
+        clctx->enqueueWfMaterialKernels(params);
+        clctx->enqueueGetCounters(&cnt);
+        clctx->enqueueWfExtRayKernel(params);
+        clctx->enqueueWfShadowRayKernel(params);
+        clctx->enqueueClearWfQueues();
+        clctx->enqueuePostprocessKernel(params);
+        clctx->finishQueue();
+        clctx->statsAsync.extensionRays += cnt.extensionQueue;
+        clctx->statsAsync.shadowRays += cnt.shadowQueue;
+        clctx->statsAsync.primaryRays += cnt.raygenQueue;
+        clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
+        clctx->updatePixelIndex(clctx->localPixels(), cnt.raygenQueue);
+        lastCnt = cnt;
+        iteration++; it++;
+        currT = now();
+        if (currT - lastLog > 0.5) log(currT);
+    }
+    log(now());
+    return csv.str();
+}
+
+} // namespace fluctus

@@ -1,0 +1,54 @@
+// tracer.hpp -- headless render driver: the host loop that sequences the wavefront kernels.
+//
+// Restates the wavefront branch of the reference's Tracer (reference: src/tracer.hpp:31-43,
+// src/tracer.cpp): resetParams (:38-52), init (:55-80), initHierarchy (:574-590, BVH cache keyed by a hash of
+// the mesh), update() WF branch (:222-266, :302-340) and runBenchmark() WF body (:362-528, CSV schema
+// `scene;time;primary;extension;shadow;total;samples` :393).  No window, no GL, no microkernel integrator
+// (out of scope).
+#pragma once
+#include <memory>
+#include <string>
+#include "hipcontext.hpp"
+
+namespace fluctus {
+
+class Tracer {
+public:
+    Tracer(int width, int height, int device = 0, uint32_t numTasks = 1u << 20);
+    ~Tracer();
+
+    void init(int width, int height, const std::string &sceneFile);             // file path or "proc:<kind>:<tris>:<seed>"
+    void setEnvMap(const std::string &hdrFile);                                   // Tracer::initEnvMap
+    void update();                                                                // one frame (iteration 0 = 2-bounce preview x3)
+    // benchmark-style iterations for `seconds` (reference: 30 s per scene) or exactly `iterations` if > 0;
+    // returns the CSV text (header + one row per 0.5 s of wall time)
+    std::string runBenchmark(double seconds, int iterations = 0);
+    void saveImage(const std::string &filename) { clctx->saveImage(filename, params); }
+
+    RenderParams &getParams() { return params; }
+    void paramsChanged() { paramsUpdatePending = true; }
+    HipContext *getContext() { return clctx.get(); }
+    Scene *getScene() { return scene.get(); }
+    uint32_t getIteration() const { return iteration; }
+    const QueueCounters &lastCounters() const { return lastCnt; }
+    std::string hierarchyCacheDir = "";                                           // empty = no on-disk BVH cache
+
+private:
+    void resetParams(int width, int height);
+    void initCamera();
+    void initPostProcessing();
+    void initAreaLight();
+    void initHierarchy();
+
+    RenderParams params;
+    std::unique_ptr<Scene> scene;
+    std::unique_ptr<EnvironmentMap> envMap;
+    std::unique_ptr<HipContext> clctx;
+    BVH *bvh = nullptr;
+    uint32_t iteration = 0;
+    bool paramsUpdatePending = true;
+    QueueCounters lastCnt {};
+    std::string sceneName;
+};
+
+} // namespace fluctus

@@ -1,0 +1,59 @@
+"""ctypes binding of the C++ headless Tracer (fluctus_amd/host/tracer.cpp) in libfluctus_host.so."""
+import ctypes as C
+import numpy as np
+from . import host
+from .wire import RENDER_PARAMS
+
+
+class Tracer:
+    def __init__(self, width, height, device=0, num_tasks=1 << 20):
+        self.L = host.lib()
+        self.h = C.c_void_p()
+        host._chk(self.L.fh_tracer_create(int(width), int(height), int(device), C.c_uint32(num_tasks), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.fh_tracer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self, width, height, scene):
+        host._chk(self.L.fh_tracer_init(self.h, int(width), int(height), scene.encode()))
+
+    def set_envmap(self, path):
+        host._chk(self.L.fh_tracer_set_envmap(self.h, path.encode()))
+
+    @property
+    def params(self):
+        p = np.zeros(1, RENDER_PARAMS)
+        host._chk(self.L.fh_tracer_params(self.h, p.ctypes.data_as(C.c_void_p), None))
+        return p.reshape(())
+
+    @params.setter
+    def params(self, p):
+        a = np.ascontiguousarray(p).reshape(1)
+        host._chk(self.L.fh_tracer_params(self.h, None, a.ctypes.data_as(C.c_void_p)))
+
+    def update(self):
+        cnt = np.zeros(8, np.uint32)
+        host._chk(self.L.fh_tracer_update(self.h, cnt.ctypes.data_as(C.c_void_p)))
+        return cnt
+
+    def run_benchmark(self, seconds=1.0, iterations=0):
+        buf = C.create_string_buffer(1 << 20)
+        host._chk(self.L.fh_tracer_run_benchmark(self.h, C.c_double(seconds), int(iterations), buf, C.c_uint64(len(buf))))
+        return buf.value.decode()
+
+    def read_pixels(self, which=0):
+        p = self.params
+        out = np.zeros((int(p["width"]) * int(p["height"]), 4), np.float32)
+        host._chk(self.L.fh_tracer_read_pixels(self.h, which, out.ctypes.data_as(C.c_void_p), C.c_uint64(out.size)))
+        return out
+
+    def save_image(self, path):
+        host._chk(self.L.fh_tracer_save_image(self.h, path.encode()))

@@ -1,0 +1,52 @@
+"""The C++ headless Tracer (host loop of the reference's Tracer::update / runBenchmark over the C ABI)."""
+import numpy as np
+import pytest
+import common
+from fluctus_amd import host, wire, driver
+
+
+def test_tracer_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from fluctus_amd.tracer import Tracer
+    with pytest.raises(RuntimeError, match="no HIP device|cannot load"):
+        Tracer(64, 64, 0, 1024)
+
+
+@pytest.mark.gpu
+def test_cpp_tracer_update_matches_oracle(tmp_path):
+    from fluctus_amd.tracer import Tracer
+    from oracle.binding import OracleContext
+    w, h, n = 96, 64, 8192
+    scene = "proc:conference:12000:43"
+    t = Tracer(w, h, 0, n)
+    t.init(w, h, scene)
+    p = t.params
+    wire.look_at(p, (0.0, 1.2, 2.6), (0.0, 0.2, 0.0))
+    p["maxBounces"], p["wfSeparateQueues"] = 6, 1
+    t.params = p
+    p = t.params
+    d = host.generate_scene("conference", 12000, 43)
+    host.build_bvh(d, "sbvh")
+    assert abs(float(p["worldRadius"]) - d.world_radius) < 1e-6 and int(p["n_tris"]) == d.tris.size
+    o = OracleContext(n, threads=8)
+    o.upload_scene(d); o.set_params(p)
+    cg = t.update()
+    co = driver.first_frame(o, p, w * h)
+    assert (cg == co).all()
+    for _ in range(5):
+        cg = t.update()
+        co = driver.benchmark_iteration(o, w * h)
+        assert (cg == co).all()
+    pg, po = t.read_pixels(0), o.read_pixels(0)
+    assert np.array_equal(pg[:, 3], po[:, 3]) and np.allclose(pg, po, rtol=1e-6, atol=1e-7)
+    o.postprocess()
+    assert np.allclose(t.read_pixels(1), o.read_pixels(1), rtol=1e-6, atol=1e-7)
+    t.save_image(str(tmp_path / "a.ppm")); t.save_image(str(tmp_path / "a.pfm"))
+    assert (tmp_path / "a.ppm").stat().st_size > w * h * 3 and (tmp_path / "a.pfm").stat().st_size > w * h * 12
+    csv = t.run_benchmark(0.0, iterations=12)
+    rows = csv.strip().split("\n")
+    assert rows[0] == "scene;time;primary;extension;shadow;total;samples" and len(rows) >= 2
+    vals = [float(x) for x in rows[-1].split(";")[1:]]
+    assert vals[2] > 0 and abs(vals[4] - (vals[1] + vals[2] + vals[3])) <= 1e-6 * vals[4]   # total = primary+extension+shadow
