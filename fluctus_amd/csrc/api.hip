@@ -10,6 +10,8 @@
 namespace flxd {
 void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
+void launch_extend_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
+void launch_shadow_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
@@ -47,6 +49,10 @@ struct flx_ctx {
     unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
     bool statsOn = false;
     int xcdRemap = 1;
+    int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
+    int refillThresh = 40;
+    int numCUs = 256;
+    uint32_t *fetch = nullptr;  // 2 x 8 shard counters for the persistent trace kernels
     // owned device allocations
     std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs;
     // async counter read-back
@@ -140,7 +146,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     const uint32_t blocks = (num_tasks + 255) / 256;
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * blocks) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * blocks))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)32 * blocks * 256)) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->fetch, 16)) return fail("hipMalloc(fetch)", hipErrorOutOfMemory);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     if (dalloc(c, c->fixedAllocs, &c->stats, 8)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->stats, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
@@ -314,13 +322,21 @@ int flx_wf_raygen(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RAYGEN); laun
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
-    { ScopedTimer t(c, FLX_K_EXTEND); launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap); }
+    {
+        ScopedTimer t(c, FLX_K_EXTEND);
+        if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
+        else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
+    }
     LAUNCHED(c); return 0;
 }
 int flx_wf_shadow(flx_ctx *c)
 {
     READY(c);
-    { ScopedTimer t(c, FLX_K_SHADOW); launch_shadow(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap); }
+    {
+        ScopedTimer t(c, FLX_K_SHADOW);
+        if (c->traceMode == 1) launch_shadow_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch + 8, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
+        else launch_shadow(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
+    }
     LAUNCHED(c); return 0;
 }
 int flx_wf_logic(flx_ctx *c, int first)
@@ -474,6 +490,8 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
+    if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 1)) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "refill_thresh") == 0 && value >= 1 && value <= 64) { c->refillThresh = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;
 }

@@ -103,21 +103,15 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Wave-aggregated queue append: one atomic per wave, slots handed out by ballot prefix.
-// (reference: atomicIncAll/atomicIncMasked, src/utils.cl:328-358; NVIDIA-only warp aggregation in
-// src/ptx_asm.cl:92-111 -- here it is the only path).  Slot order within the queue is not
-// observable for the extension queue.
-__device__ __forceinline__ uint32_t wave_append(uint32_t *counter, bool pred)
-{
-    uint64_t mask = __ballot(pred);
-    uint32_t base = 0;
-    if (mask != 0ull) {
-        uint32_t n = (uint32_t)__popcll(mask);
-        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane_id() == leader) base = atomicAdd(counter, n);
-        base = __shfl(base, (int)leader, 64);
-    }
-    return base + mbcnt(mask);
-}
+// EXTENSION-QUEUE APPENDS WITHOUT ATOMICS.  The reference appends to the extension queue with one
+// atomic_inc per work-item (src/wf_raygen.cl:69-70, src/wf_mat_diffuse.cl:64-65; src/utils.cl:328-358).
+// A single hot counter saturates at ~88 atomics/us on MI355X, so even one atomic per WAVE cost
+// ~150 us per iteration here (13 k waves).  Every appender consumes a compacted source queue whose
+// length is already known, so the slot is computed instead: slot = extBase + (lengths of the source
+// queues appended before this one in the same call) + index in the own source queue.  extBase is the
+// extension counter as left by the previous call; a 1-thread kernel adds the appended total
+// afterwards (stream order).  The extension queue thus is the concatenation
+// [raygen | diffuse | glossy | ggxRefl | ggxRefr | delta] in source order: deterministic.
+// (k_bump_extension / launch_bump_extension live in misc.hip)
 
 } // namespace flxd

@@ -209,14 +209,15 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
     }
 }
 
-// one block: exclusive scan of each list's per-block counts; totals are added to the queue counters
+// one block per list: exclusive scan of the list's per-block counts; the total is added to its queue counter
 __global__ __launch_bounds__(1024) void k_queue_scan(LogicAux aux, uint32_t *counters)
 {
     __shared__ uint32_t s_part[1024];
     const uint32_t listToCounter[NUM_LISTS] = {FLX_Q_RAYGEN, FLX_Q_SHADOW, FLX_Q_DIFFUSE, FLX_Q_GLOSSY, FLX_Q_GGX_REFL, FLX_Q_GGX_REFR, FLX_Q_DELTA};
     const uint32_t nb = aux.numBlocks;
     const uint32_t per = (nb + 1023u) / 1024u;
-    for (int l = 0; l < NUM_LISTS; l++) {
+    {
+        const int l = blockIdx.x;                     // one block per list
         const uint32_t *cnt = aux.blockCounts + (size_t)l * nb;
         uint32_t *off = aux.blockOffsets + (size_t)l * nb;
         const uint32_t base = counters[listToCounter[l]];
@@ -273,7 +274,7 @@ void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene 
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
     LogicAux aux{member, blockCounts, blockOffsets, blocks};
     hipLaunchKernelGGL(k_logic, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
-    hipLaunchKernelGGL(k_queue_scan, dim3(1), dim3(1024), 0, s, aux, qs.counters);
+    hipLaunchKernelGGL(k_queue_scan, dim3(NUM_LISTS), dim3(1024), 0, s, aux, qs.counters);
     hipLaunchKernelGGL(k_queue_scatter, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, qs, aux, st.numTasks);
 }
 

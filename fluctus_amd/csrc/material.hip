@@ -342,7 +342,7 @@ __device__ __forceinline__ f3 sample_ideal_dielectric(const Scene &sc, const Sur
 enum { USE_DIFFUSE = 1, USE_GLOSSY = 2, USE_GGX_REFL = 4, USE_GGX_REFR = 8, USE_DELTA = 16, USE_ALL = 31 };
 
 template <int USE>
-__global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Scene sc, int queueId)
+__global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Scene sc, int queueId, uint32_t earlierMask)
 {
     const uint32_t qlen = qs.counters[queueId];
     const uint32_t idx = blockIdx.x * MAT_BLOCK + threadIdx.x;
@@ -398,20 +398,26 @@ __global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Sce
         st.rec[S_ORIG][gid] = mk4(orig, pdfW);
         st.rec[S_DIR][gid] = mk4(newDir, d4.w);
     }
-    const uint32_t slot = wave_append(&qs.counters[FLX_Q_EXTENSION], active);
-    if (active) qs.q[FLX_Q_EXTENSION][slot] = gid;
+    if (active) {
+        // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)
+        uint32_t base = qs.counters[FLX_Q_EXTENSION];
+        for (int q = FLX_Q_DIFFUSE; q < FLX_NUM_QUEUES; q++) if (earlierMask & (1u << q)) base += qs.counters[q];
+        qs.q[FLX_Q_EXTENSION][base + idx] = gid;
+    }
 }
 
-static void launch_one(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, int queueId, int use)
+void launch_bump_extension(hipStream_t s, uint32_t *counters, uint32_t srcMask);
+
+static void launch_one(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, int queueId, int use, uint32_t earlierMask)
 {
     uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK;
     switch (use) {
-    case USE_DIFFUSE: hipLaunchKernelGGL(k_material<USE_DIFFUSE>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
-    case USE_GLOSSY: hipLaunchKernelGGL(k_material<USE_GLOSSY>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
-    case USE_GGX_REFL: hipLaunchKernelGGL(k_material<USE_GGX_REFL>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
-    case USE_GGX_REFR: hipLaunchKernelGGL(k_material<USE_GGX_REFR>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
-    case USE_DELTA: hipLaunchKernelGGL(k_material<USE_DELTA>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
-    default: hipLaunchKernelGGL(k_material<USE_ALL>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId); break;
+    case USE_DIFFUSE: hipLaunchKernelGGL(k_material<USE_DIFFUSE>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
+    case USE_GLOSSY: hipLaunchKernelGGL(k_material<USE_GLOSSY>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
+    case USE_GGX_REFL: hipLaunchKernelGGL(k_material<USE_GGX_REFL>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
+    case USE_GGX_REFR: hipLaunchKernelGGL(k_material<USE_GGX_REFR>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
+    case USE_DELTA: hipLaunchKernelGGL(k_material<USE_DELTA>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
+    default: hipLaunchKernelGGL(k_material<USE_ALL>, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, queueId, earlierMask); break;
     }
 }
 
@@ -419,13 +425,16 @@ static void launch_one(hipStream_t s, const State &st, const Queues &qs, const S
 void launch_materials(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, uint32_t separateQueues)
 {
     if (separateQueues) {
-        launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE);
-        launch_one(s, st, qs, sc, FLX_Q_GLOSSY, USE_GLOSSY);
-        launch_one(s, st, qs, sc, FLX_Q_GGX_REFL, USE_GGX_REFL);
-        launch_one(s, st, qs, sc, FLX_Q_GGX_REFR, USE_GGX_REFR);
-        launch_one(s, st, qs, sc, FLX_Q_DELTA, USE_DELTA);
+        const uint32_t D = 1u << FLX_Q_DIFFUSE, G = 1u << FLX_Q_GLOSSY, RL = 1u << FLX_Q_GGX_REFL, RR = 1u << FLX_Q_GGX_REFR, DL = 1u << FLX_Q_DELTA;
+        launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, 0u);
+        launch_one(s, st, qs, sc, FLX_Q_GLOSSY, USE_GLOSSY, D);
+        launch_one(s, st, qs, sc, FLX_Q_GGX_REFL, USE_GGX_REFL, D | G);
+        launch_one(s, st, qs, sc, FLX_Q_GGX_REFR, USE_GGX_REFR, D | G | RL);
+        launch_one(s, st, qs, sc, FLX_Q_DELTA, USE_DELTA, D | G | RL | RR);
+        launch_bump_extension(s, qs.counters, D | G | RL | RR | DL);
     } else {
-        launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_ALL);
+        launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_ALL, 0u);
+        launch_bump_extension(s, qs.counters, 1u << FLX_Q_DIFFUSE);
     }
 }
 

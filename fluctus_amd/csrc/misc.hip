@@ -82,8 +82,20 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         st.rec[S_THR][gid] = mk4u(mk3(1.0f), seed);
         init_path_state(st, gid, 2.0f * p.worldRadius);
     }
-    const uint32_t slot = wave_append(&qs.counters[FLX_Q_EXTENSION], active);
-    if (active) qs.q[FLX_Q_EXTENSION][slot] = gid;
+    if (active) qs.q[FLX_Q_EXTENSION][qs.counters[FLX_Q_EXTENSION] + gd] = gid;   // extBase + index (see flx_device.h)
+}
+
+__global__ void k_bump_extension(uint32_t *counters, uint32_t srcMask)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t add = 0;
+        for (int q = 0; q < FLX_NUM_QUEUES; q++) if (srcMask & (1u << q)) add += counters[q];
+        counters[FLX_Q_EXTENSION] += add;
+    }
+}
+void launch_bump_extension(hipStream_t s, uint32_t *counters, uint32_t srcMask)
+{
+    hipLaunchKernelGGL(k_bump_extension, dim3(1), dim3(64), 0, s, counters, srcMask);
 }
 
 __device__ __forceinline__ f3 uc2_func(f3 x)
@@ -183,6 +195,7 @@ void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame 
 void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
 {
     hipLaunchKernelGGL(k_raygen, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
+    hipLaunchKernelGGL(k_bump_extension, dim3(1), dim3(64), 0, s, qs.counters, 1u << FLX_Q_RAYGEN);
 }
 void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
 {

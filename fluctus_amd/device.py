@@ -26,7 +26,8 @@ KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "mater
 
 
 def lib_path():
-    return os.path.join(_HERE, "libfluctus_hip.so")
+    # FLX_HIP_LIB selects an A/B build of the same library (scripts/build_variants.py); default = the shipped one
+    return os.environ.get("FLX_HIP_LIB") or os.path.join(_HERE, "libfluctus_hip.so")
 
 
 def lib():

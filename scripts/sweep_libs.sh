@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of library variants: scripts/sweep_libs.sh "<bench args>" lib1 lib2 ...
+ARGS="$1"; shift
+for v in "$@"; do
+  echo "=== $v $ARGS"
+  FLX_HIP_LIB=$PWD/variants/libfluctus_hip_$v.so python bench.py --steps 40 --warmup 20 --no-cpu-baseline $ARGS 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j = json.loads(l); k = j['kernel_ms_avg']
+        print('Mrays/s %.0f  ms/step %.3f  ext %.3f shadow %.3f logic %.3f mat %.3f raygen %.3f' % (j['value'], j['ms_per_step'], k.get('extend',0), k.get('shadow',0), k.get('logic',0), k.get('materials',0), k.get('raygen',0)))
+"
+done

@@ -15,10 +15,21 @@ from fluctus_amd import host, wire, driver
 pytestmark = pytest.mark.gpu
 
 
+TRACE_MODE = {"mode": 1, "thresh": 40}
+
+
+@pytest.fixture(params=[(0, 40), (1, 40), (1, 64), (1, 8)], ids=["thread-per-ray", "persistent-t40", "persistent-t64", "persistent-t8"], autouse=True)
+def trace_mode(request):
+    TRACE_MODE["mode"], TRACE_MODE["thresh"] = request.param
+    yield
+
+
 def _ctxs(d, p, n, env=None):
     from fluctus_amd.device import HipContext
     from oracle.binding import OracleContext
     g, o = HipContext(n), OracleContext(n, threads=8)
+    g.set_option("trace_mode", TRACE_MODE["mode"])
+    g.set_option("refill_thresh", TRACE_MODE["thresh"])
     for c in (g, o):
         c.upload_scene(d)
         if env is not None:
@@ -36,8 +47,7 @@ def _compare(g, o, what, check_queues=True):
         for q in range(8):
             n = int(co[q])
             qa, qb = g.queue_read(q)[:n], o.queue_read(q)[:n]
-            if q == Q.EXTENSION:       # extension-queue order is unobservable (wave-aggregated appends)
-                qa, qb = np.sort(qa), np.sort(qb)
+            # all queues, the extension queue included, are in canonical order (stable compaction + computed slots)
             assert np.array_equal(qa, qb), f"{what}: queue {q} differs"
     fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
     assert not fails, f"{what}: " + "; ".join(fails[:5])

@@ -49,4 +49,4 @@ def test_cpp_tracer_update_matches_oracle(tmp_path):
     rows = csv.strip().split("\n")
     assert rows[0] == "scene;time;primary;extension;shadow;total;samples" and len(rows) >= 2
     vals = [float(x) for x in rows[-1].split(";")[1:]]
-    assert vals[2] > 0 and abs(vals[4] - (vals[1] + vals[2] + vals[3])) <= 1e-6 * vals[4]   # total = primary+extension+shadow
+    assert vals[2] > 0 and abs(vals[4] - (vals[1] + vals[2] + vals[3])) <= 1e-4 * vals[4]   # total = primary+extension+shadow
