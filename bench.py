@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--width", type=int, default=WIDTH)
     ap.add_argument("--height", type=int, default=HEIGHT)
     ap.add_argument("--num-tasks", type=int, default=NUM_TASKS)
-    ap.add_argument("--xcd-remap", type=int, default=1)
+    ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
     ap.add_argument("--refill-thresh", type=int, default=40)
     args = ap.parse_args()

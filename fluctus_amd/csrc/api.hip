@@ -48,7 +48,7 @@ struct flx_ctx {
     unsigned long long *stats = nullptr;   // device, 7 counters
     unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
     bool statsOn = false;
-    int xcdRemap = 1;
+    int xcdRemap = 0;           // 1: each XCD gets a contiguous eighth of the queue (measured slower: round-robin keeps all XCDs on the same part of the tree)
     int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
     int refillThresh = 40;
     int numCUs = 256;
