@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--num-tasks", type=int, default=NUM_TASKS)
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--refill-thresh", type=int, default=40)
     args = ap.parse_args()
 
@@ -135,6 +136,7 @@ def main():
     ctx = device.HipContext(args.num_tasks, device_index=local_rank)
     ctx.set_option("xcd_remap", args.xcd_remap)
     ctx.set_option("trace_mode", args.trace_mode)
+    ctx.set_option("overlap", args.overlap)
     ctx.set_option("refill_thresh", args.refill_thresh)
     ctx.upload_scene(d)
     ctx.upload_envmap(env)

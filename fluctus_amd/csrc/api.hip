@@ -32,6 +32,11 @@ struct PendingEvent { int kernel; hipEvent_t a, b; };
 struct flx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;              // the shadow kernel runs here, concurrently with the extension kernel
+    hipEvent_t evPreExt = nullptr, evShadow = nullptr;
+    bool overlapOK = false;                     // true between flx_wf_extend and the next enqueue
+    int overlap = 1;
+    uint32_t *spill2 = nullptr;
     uint32_t numTasks = 0;
     std::string err;
     State st {};
@@ -85,9 +90,9 @@ static hipEvent_t getEvent(flx_ctx *c)
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 struct ScopedTimer {
-    flx_ctx *c; int k; hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(flx_ctx *c_, int k_) : c(c_), k(k_) { if (c->profile) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, c->stream); } }
-    ~ScopedTimer() { if (c->profile) { (void)hipEventRecord(b, c->stream); c->events.push_back({k, a, b}); } }
+    flx_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) { if (c->profile) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); } }
+    ~ScopedTimer() { if (c->profile) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
 };
 
 static uint32_t localPixels(const flx_ctx *c)
@@ -128,6 +133,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
     c->st.numTasks = num_tasks;
     for (int r = 0; r < S_NUM_REC; r++) {
@@ -146,6 +153,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     const uint32_t blocks = (num_tasks + 255) / 256;
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * blocks) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * blocks))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->spill2, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->fetch, 16)) return fail("hipMalloc(fetch)", hipErrorOutOfMemory);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
@@ -183,6 +191,9 @@ int flx_destroy(flx_ctx *c)
     if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->evPreExt) (void)hipEventDestroy(c->evPreExt);
+    if (c->evShadow) (void)hipEventDestroy(c->evShadow);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -314,7 +325,7 @@ int flx_set_partition(flx_ctx *c, uint32_t rank, uint32_t nranks)
 }
 uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 
-#define READY(c) do { NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+#define READY(c) do { (c)->overlapOK = false; NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
 int flx_wf_reset(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
@@ -322,22 +333,36 @@ int flx_wf_raygen(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RAYGEN); laun
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
+    if (c->overlap) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));      // "everything enqueued before the extension kernel"
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
-    LAUNCHED(c); return 0;
+    LAUNCHED(c);
+    c->overlapOK = c->overlap != 0;
+    return 0;
 }
 int flx_wf_shadow(flx_ctx *c)
 {
+    // The shadow kernel touches {shadowOrig, shadowDir, shadow queue} -> shadowRayBlocked, the extension kernel
+    // {orig, dir, extension queue} -> hit + pathLen: disjoint.  When it directly follows flx_wf_extend (the reference's
+    // order, src/tracer.cpp:250-251) it is launched on a second stream that only waits for the work enqueued BEFORE the
+    // extension kernel, so the two traversals share the machine and fill each other's tails; the main stream then waits
+    // for it, which keeps the single-in-order-queue semantics for everything that follows.
+    const bool overlapped = c->overlapOK;
     READY(c);
+    hipStream_t s = c->stream;
+    if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, c->evPreExt, 0)); }
     {
-        ScopedTimer t(c, FLX_K_SHADOW);
-        if (c->traceMode == 1) launch_shadow_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch + 8, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
-        else launch_shadow(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
+        ScopedTimer t(c, FLX_K_SHADOW, s);
+        uint32_t *spill = overlapped ? c->spill2 : c->spill;
+        if (c->traceMode == 1) launch_shadow_persistent(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->fetch + 8, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
+        else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
-    LAUNCHED(c); return 0;
+    LAUNCHED(c);
+    if (overlapped) { HIPCHK(c, hipEventRecord(c->evShadow, s)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadow, 0)); }
+    return 0;
 }
 int flx_wf_logic(flx_ctx *c, int first)
 {
@@ -490,6 +515,7 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
+    if (name && strcmp(name, "overlap") == 0 && (value == 0 || value == 1)) { c->overlap = value; return 0; }
     if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 1)) { c->traceMode = value; return 0; }
     if (name && strcmp(name, "refill_thresh") == 0 && value >= 1 && value <= 64) { c->refillThresh = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
