@@ -225,9 +225,27 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         trirecs[s].c = make_float4(t.v2.p.x, t.v2.p.y, t.v2.p.z, 0.0f);
     }
     // 2. inner-node records: both child boxes + refs; DFS numbering of inner nodes only
+    // Numbering: the top of the tree first, in BFS order (these records are cached in LDS by the trace kernels), then the
+    // remaining inner nodes in the reference's DFS order (subtrees stay contiguous for the caches).
     std::vector<int32_t> innerId(nnodes, -1);
-    uint32_t ninner = 0;
-    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) innerId[i] = (int32_t)ninner++;
+    uint32_t ninner = 0, topCount = 0;
+    {
+        const uint32_t TOP_MAX = 1023;
+        std::vector<uint32_t> frontier, next;
+        if (nodes[0].nPrims == 0) frontier.push_back(0);
+        while (!frontier.empty() && ninner + frontier.size() <= TOP_MAX) {
+            next.clear();
+            for (uint32_t ni : frontier) {
+                innerId[ni] = (int32_t)ninner++;
+                uint32_t l = ni + 1, r = nodes[ni].iStartOrRight;
+                if (l < nnodes && nodes[l].nPrims == 0) next.push_back(l);
+                if (r < nnodes && nodes[r].nPrims == 0) next.push_back(r);
+            }
+            frontier.swap(next);
+        }
+        topCount = ninner;
+        for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0 && innerId[i] < 0) innerId[i] = (int32_t)ninner++;
+    }
     auto childRef = [&](uint32_t ni, bool &ok) -> uint32_t {
         if (ni >= nnodes) { ok = false; return 0; }
         const flx_node &n = nodes[ni];
@@ -285,6 +303,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     if (texbytes) HIPCHK(c, hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
+    c->sc.topCount = topCount;
     return 0;
 }
 

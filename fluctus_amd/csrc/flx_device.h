@@ -76,6 +76,7 @@ struct Scene {
     const flx_texdesc *texdesc;
     const uint8_t *texdata;
     uint32_t rootRef;             // BNode 0 (inner) -- tiny scenes get a synthetic root
+    uint32_t topCount;            // BNodes [0, topCount) are the top of the tree in BFS order (LDS-cacheable)
     // environment map
     const float4 *envRGBA;
     const float *probTable, *pdfTable;

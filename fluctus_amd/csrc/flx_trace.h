@@ -15,6 +15,10 @@ namespace flxd {
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1        // __launch_bounds__ 2nd argument (min waves per SIMD -> VGPR cap)
 #endif
+#ifndef TOP_NODES
+#define TOP_NODES 0              // >0: cache the first TOP_NODES inner nodes (BFS order) in LDS per block.  Measured SLOWER on MI355X
+                                 // (top levels already hit the 32 KiB L1; the LDS copy costs occupancy) -- kept as an A/B switch, default off
+#endif
 #define MAX_LEVELS 64
 
 struct TraceAux {

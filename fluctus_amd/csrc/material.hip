@@ -342,10 +342,9 @@ __device__ __forceinline__ f3 sample_ideal_dielectric(const Scene &sc, const Sur
 enum { USE_DIFFUSE = 1, USE_GLOSSY = 2, USE_GGX_REFL = 4, USE_GGX_REFR = 8, USE_DELTA = 16, USE_ALL = 31 };
 
 template <int USE>
-__global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Scene sc, int queueId, uint32_t earlierMask)
+__device__ __forceinline__ void material_body(const State &st, const Queues &qs, const Scene &sc, int queueId, uint32_t idx, uint32_t earlierMask)
 {
     const uint32_t qlen = qs.counters[queueId];
-    const uint32_t idx = blockIdx.x * MAT_BLOCK + threadIdx.x;
     const bool active = idx < qlen;
     uint32_t gid = 0;
     if (active) {
@@ -406,6 +405,27 @@ __global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Sce
     }
 }
 
+template <int USE>
+__global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Scene sc, int queueId, uint32_t earlierMask)
+{
+    material_body<USE>(st, qs, sc, queueId, blockIdx.x * MAT_BLOCK + threadIdx.x, earlierMask);
+}
+
+// The four small queues (glossy, GGX reflection, GGX refraction, delta) in ONE launch: each block serves one queue
+// (block ranges follow the queue lengths), so waves stay BSDF-uniform like in the per-queue kernels, but three
+// near-empty 4096-block launches per iteration disappear.
+__global__ __launch_bounds__(MAT_BLOCK) void k_material_rest(State st, Queues qs, Scene sc)
+{
+    uint32_t b = blockIdx.x;
+    uint32_t earlier = 1u << FLX_Q_DIFFUSE;
+    for (int q = FLX_Q_GLOSSY; q <= FLX_Q_DELTA; q++) {
+        const uint32_t nb = (qs.counters[q] + MAT_BLOCK - 1) / MAT_BLOCK;
+        if (b < nb) { material_body<USE_GLOSSY | USE_GGX_REFL | USE_GGX_REFR | USE_DELTA>(st, qs, sc, q, b * MAT_BLOCK + threadIdx.x, earlier); return; }
+        b -= nb;
+        earlier |= 1u << q;
+    }
+}
+
 void launch_bump_extension(hipStream_t s, uint32_t *counters, uint32_t srcMask);
 
 static void launch_one(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, int queueId, int use, uint32_t earlierMask)
@@ -427,10 +447,10 @@ void launch_materials(hipStream_t s, const State &st, const Queues &qs, const Sc
     if (separateQueues) {
         const uint32_t D = 1u << FLX_Q_DIFFUSE, G = 1u << FLX_Q_GLOSSY, RL = 1u << FLX_Q_GGX_REFL, RR = 1u << FLX_Q_GGX_REFR, DL = 1u << FLX_Q_DELTA;
         launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, 0u);
-        launch_one(s, st, qs, sc, FLX_Q_GLOSSY, USE_GLOSSY, D);
-        launch_one(s, st, qs, sc, FLX_Q_GGX_REFL, USE_GGX_REFL, D | G);
-        launch_one(s, st, qs, sc, FLX_Q_GGX_REFR, USE_GGX_REFR, D | G | RL);
-        launch_one(s, st, qs, sc, FLX_Q_DELTA, USE_DELTA, D | G | RL | RR);
+        {   // glossy + ggxRefl + ggxRefr + delta (at most numTasks paths in total -> blocks + 4 partial blocks)
+            uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK + 4;
+            hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc);
+        }
         launch_bump_extension(s, qs.counters, D | G | RL | RR | DL);
     } else {
         launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_ALL, 0u);

@@ -10,6 +10,9 @@
 //  * the traversal stack lives in LDS, laid out [level][lane] so a wave's push/pop is one
 //    conflict-free ds_write_b32/ds_read_b32 (the reference's `uint stack[64]` is private memory,
 //    i.e. scratch on a wave64 machine); levels >= LDS_LEVELS spill to a global side buffer;
+//  * the top of the tree (the first TOP_NODES inner nodes in BFS order, visited by every ray) is copied into LDS by
+//    each block and read from there: ~half of all node visits never reach the L1/L2 gather path, which is what bounds
+//    this kernel (scripts/ubench/gather_sweep.hip: random 64-B gathers run at 55-200 G records/s depending on cache level);
 //  * the current node is kept in a register ("push farther, continue with closer"), which is the
 //    same visit order as the reference's push-both-pop-one;
 //  * triangles are 48-B position-only records in leaf order; normals/uvs/matId are fetched once
@@ -22,7 +25,7 @@
 namespace flxd {
 
 template <bool ANY_HIT, bool STATS>
-__device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
+__device__ __forceinline__ bool traverse(const Scene &sc, const float4 *s_top, uint32_t topCount, Stack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
                                          int &tribest, uint32_t &nInner, uint32_t &nTri)
 {
     const f3 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -30,8 +33,19 @@ __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f
     uint32_t cur = sc.rootRef;
     for (;;) {
         if (!(cur & FLX_LEAF_BIT)) {
-            const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
-            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            float4 n0, n1, n2, n3;
+            if (TOP_NODES > 0) {
+                // top of the tree from LDS (4 x ds_read_b128), the rest from memory; both groups of loads are issued
+                // before either result is used so their latencies overlap in a wave that has lanes of both kinds
+                const bool top = cur < topCount;
+                float4 g0, g1, g2, g3, l0, l1, l2, l3;
+                if (!top) { const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur); g0 = np[0]; g1 = np[1]; g2 = np[2]; g3 = np[3]; }
+                if (top) { const float4 *np = s_top + cur * 4u; l0 = np[0]; l1 = np[1]; l2 = np[2]; l3 = np[3]; }
+                n0 = top ? l0 : g0; n1 = top ? l1 : g1; n2 = top ? l2 : g2; n3 = top ? l3 : g3;
+            } else {
+                const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
+                n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+            }
             if (STATS) nInner++;
             float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
             float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
@@ -74,6 +88,13 @@ template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
+    __shared__ float4 s_top[(TOP_NODES > 0 ? TOP_NODES : 1) * 4];
+    const uint32_t topCount = sc.topCount < (uint32_t)TOP_NODES ? sc.topCount : (uint32_t)TOP_NODES;
+    if (TOP_NODES > 0) {                                          // every thread of the block helps, including those without a ray
+        const float4 *src = reinterpret_cast<const float4 *>(sc.bnodes);
+        for (uint32_t i = threadIdx.x; i < topCount * 4u; i += TRACE_BLOCK) s_top[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t qlen = qs.counters[FLX_Q_EXTENSION];
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, xcdRemap);
     const uint32_t idx = blk * TRACE_BLOCK + threadIdx.x;
@@ -92,7 +113,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     float t = FLX_FLT_MAX, u = 0.0f, v = 0.0f;
     int tri = -1;
     uint32_t nInner = 0, nTri = 0;
-    traverse<false, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
+    traverse<false, STATS>(sc, s_top, topCount, stk, orig, dir, t, u, v, tri, nInner, nTri);
 
     // commit: shading attributes of the winning triangle (reference: src/bvh.cl:271-279)
     f3 P = mk3(0.0f), N = mk3(0.0f);
@@ -140,6 +161,13 @@ template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_shadow(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
+    __shared__ float4 s_top[(TOP_NODES > 0 ? TOP_NODES : 1) * 4];
+    const uint32_t topCount = sc.topCount < (uint32_t)TOP_NODES ? sc.topCount : (uint32_t)TOP_NODES;
+    if (TOP_NODES > 0) {                                          // every thread of the block helps, including those without a ray
+        const float4 *src = reinterpret_cast<const float4 *>(sc.bnodes);
+        for (uint32_t i = threadIdx.x; i < topCount * 4u; i += TRACE_BLOCK) s_top[i] = src[i];
+        __syncthreads();
+    }
     const uint32_t qlen = qs.counters[FLX_Q_SHADOW];
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, xcdRemap);
     const uint32_t idx = blk * TRACE_BLOCK + threadIdx.x;
@@ -162,7 +190,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_shadow(State s
     if (p.useAreaLight) { float tl = lenL; occluded = light_quad(p.areaLight, orig, dir, &tl); }
     if (!occluded) {
         float t = lenL, u, v; int tri;
-        occluded = traverse<true, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
+        occluded = traverse<true, STATS>(sc, s_top, topCount, stk, orig, dir, t, u, v, tri, nInner, nTri);
     }
     st.blocked[gid] = occluded ? 1u : 0u;
 
