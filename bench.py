@@ -194,6 +194,13 @@ def main():
     ext_ms, ext_n = prof["extend"]
     rays_per_launch = ext / world / max(1, args.steps)
     achieved = (bytes_per_ext_ray * rays_per_launch) / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 if ext_ms > 0 else 0.0
+    # k_extend shares the machine with the concurrent k_shadow; the pair's span gives the combined traversal rate
+    span_ms, span_n = prof.get("trace_span", (0.0, 0))
+    bytes_per_sh_ray = sh_bytes / max(1, st["shadow_rays"])
+    combined = None
+    if span_n:
+        combined_bytes = bytes_per_ext_ray * rays_per_launch + bytes_per_sh_ray * (sh / world / max(1, args.steps))
+        combined = combined_bytes / (span_ms / span_n * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
@@ -242,7 +249,11 @@ def main():
                          "avg_inner_visits": st["ext_inner"] / max(1, st["ext_rays"]),
                          "avg_tri_tests": st["ext_tri"] / max(1, st["ext_rays"]),
                          "hit_fraction": st["ext_hits"] / max(1, st["ext_rays"]),
-                         "launch_ms": ext_ms / max(1, ext_n)},
+                         "launch_ms": ext_ms / max(1, ext_n),
+                         "note": "k_extend runs concurrently with k_shadow (two streams); 'concurrent_traversal' = (extension + shadow "
+                                 "algorithmic bytes) / span of the pair",
+                         "concurrent_traversal": ({"achieved": combined, "frac": combined / HBM_PEAK_GBS, "span_ms": span_ms / span_n,
+                                                   "shadow_bytes_per_ray": bytes_per_sh_ray} if combined else None)},
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms

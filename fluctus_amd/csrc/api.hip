@@ -66,6 +66,7 @@ struct flx_ctx {
     std::vector<PendingCounters> pending;
     // profiling
     bool profile = false;
+    hipEvent_t spanStart = nullptr;             // pending FLX_K_TRACE_SPAN start (recorded in flx_wf_extend)
     std::vector<PendingEvent> events;
     std::vector<hipEvent_t> eventPool;
     double kMs[FLX_K_COUNT] = {0}; uint64_t kLaunches[FLX_K_COUNT] = {0};
@@ -353,6 +354,7 @@ int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
     if (c->overlap) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));      // "everything enqueued before the extension kernel"
+    if (c->profile) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
@@ -381,6 +383,10 @@ int flx_wf_shadow(flx_ctx *c)
     }
     LAUNCHED(c);
     if (overlapped) { HIPCHK(c, hipEventRecord(c->evShadow, s)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadow, 0)); }
+    if (c->profile && overlapped && c->spanStart) {
+        hipEvent_t b = getEvent(c); (void)hipEventRecord(b, c->stream);       // after the join: both traversals done
+        c->events.push_back({FLX_K_TRACE_SPAN, c->spanStart, b}); c->spanStart = nullptr;
+    }
     return 0;
 }
 int flx_wf_logic(flx_ctx *c, int first)

@@ -22,7 +22,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option"]
 
-KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6}
+KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7}
 
 
 def lib_path():

@@ -103,7 +103,9 @@ void *flx_stream(flx_ctx *ctx);
 /* ---- measurement.  Per-kernel HIP-event timing on the context's stream (the reference attaches
  * cl::Events to the two trace kernels, src/clcontext.cpp:673-701,780,786).  kernel ids: */
 enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FLX_K_LOGIC = 4, FLX_K_MATERIALS = 5,
-       FLX_K_POSTPROCESS = 6, FLX_K_COUNT = 7 };
+       FLX_K_POSTPROCESS = 6,
+       FLX_K_TRACE_SPAN = 7,   /* start of the extension kernel .. end of the (concurrent) shadow kernel */
+       FLX_K_COUNT = 8 };
 int flx_profile_enable(flx_ctx *ctx, int on);
 /* after flx_finish(): accumulated milliseconds and launch count since the last reset */
 int flx_profile_get(flx_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
