@@ -188,3 +188,116 @@ def test_large_queue_properties():
     assert int(px[:, 3].sum()) == total_new
     st = g.state_export().view(np.uint32)
     assert (st[COL.PATH_LEN] <= int(p["maxBounces"]) + 1).all()
+
+
+def test_full_size_kitchen_properties_and_determinism():
+    """BASELINE.json configs[1] at full size (kitchen-proc ~0.5 M triangles, 1920x1080, 8 bounces, env-map MIS, 1 M paths):
+    too big for the oracle, so size-independent properties are checked, and two independent runs must agree bit for bit."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload()
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    outs = []
+    for run in range(2):
+        g = HipContext(n)
+        g.set_option("trace_mode", TRACE_MODE["mode"])
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); driver.reset_renderer(g)
+        cnts = []
+        for it in range(12):
+            c = driver.benchmark_iteration(g, npix)
+            cnts.append(c)
+            assert int(c[Q.RAYGEN]) + int(c[3:8].sum()) == n           # regenerate or continue, exactly once
+            assert int(c[Q.EXTENSION]) == n and int(c[Q.SHADOW]) <= int(c[3:8].sum())
+        st = g.state_export()
+        px = g.read_pixels(0)
+        assert np.isfinite(px).all() and (px[:, 3] >= 0).all()
+        assert int(px[:, 3].sum()) == sum(int(c[Q.RAYGEN]) for c in cnts[1:])
+        iu = st.view(np.uint32)
+        assert (iu[COL.PATH_LEN] <= int(p["maxBounces"]) + 1).all() and (iu[COL.PIXEL_INDEX] < npix).all()
+        hit = iu[COL.HIT_I].view(np.int32)
+        assert ((hit >= -1) & (hit < d.tris.size)).all()
+        nrm = np.sqrt(st[COL.DIR] ** 2 + st[COL.DIR + 1] ** 2 + st[COL.DIR + 2] ** 2)
+        live = iu[COL.PATH_LEN] > 0
+        assert np.allclose(nrm[live & (st[COL.T] + st[COL.T + 1] + st[COL.T + 2] > 0)], 1.0, atol=1e-3)
+        outs.append((np.stack(cnts), st, px))
+        g.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert not common.state_diff(outs[0][1], outs[1][1], 0.0, 0.0)
+    assert np.array_equal(outs[0][2][:, 3], outs[1][2][:, 3]) and np.allclose(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-7)
+
+
+def test_c_abi_error_paths():
+    """Errors come back as return codes + flx_last_error, never as crashes or silent fallbacks."""
+    import ctypes as C
+    from fluctus_amd import device
+    L = device.lib()
+    h = C.c_void_p()
+    assert L.flx_create(0, C.c_uint32(0), C.byref(h)) != 0 and b"num_tasks" in L.flx_last_error(None)
+    assert L.flx_create(99, C.c_uint32(1024), C.byref(h)) != 0 and b"device" in L.flx_last_error(None)
+    g = device.HipContext(1024)
+    with pytest.raises(RuntimeError, match="set params first"):
+        g.wf_reset()
+    d = common.simple_scene()
+    p = common.scene_params(d, 16, 16)
+    g.set_params(p)
+    with pytest.raises(RuntimeError, match="upload a scene first"):
+        g.wf_extend()
+    bad = host.SceneData()
+    bad.tris, bad.nodes, bad.materials, bad.texdesc, bad.texdata = d.tris, d.nodes, d.materials, d.texdesc, d.texdata
+    bad.indices = d.indices.copy(); bad.indices[3] = d.tris.size + 7
+    with pytest.raises(RuntimeError, match="index out of range"):
+        g.upload_scene(bad)
+    bad.indices = d.indices
+    bad.tris = d.tris.copy(); bad.tris["matId"][0] = 5
+    with pytest.raises(RuntimeError, match="material id out of range"):
+        g.upload_scene(bad)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        g.set_option("no_such_option", 1)
+    p0 = p.copy(); p0["width"] = 0
+    with pytest.raises(RuntimeError, match="zero-sized"):
+        g.set_params(p0)
+    g.upload_scene(d); g.set_params(p)
+    driver.reset_renderer(g)
+    driver.benchmark_iteration(g, 256)          # still usable after the errors
+
+
+def test_single_leaf_scene_and_deep_stack_spill():
+    """Edge cases of the traversal layout: a scene that is ONE leaf (synthetic root) and a degenerate, very deep tree
+    (median-split chain) that overflows the LDS stack levels into the global spill area."""
+    from fluctus_amd.device import HipContext
+    from oracle.binding import OracleContext
+    # (a) two triangles -> the whole BVH is a single leaf node
+    d = common.small_mesh_scene(n=6)
+    d.tris = d.tris[:2].copy()
+    d.materials = np.array([common.default_material()], wire.MATERIAL)
+    d.texdesc = np.zeros(0, wire.TEXDESC); d.texdata = np.zeros(0, np.uint8)
+    host.build_bvh(d, "sbvh")
+    assert d.nodes.size == 1 and d.nodes[0]["nPrims"] == 2
+    p = common.scene_params(d, 32, 32, maxBounces=3)
+    g, o = _ctxs(d, p, 1024)
+    _free_run(g, o, 32 * 32, 6)
+    # (b) hand-built right-leaning chain of 40 levels: every inner node = {leaf with 1 triangle, rest}
+    d = common.small_mesh_scene(n=6)
+    d.tris = d.tris[:41].copy()
+    d.materials = np.array([common.default_material()], wire.MATERIAL)
+    d.texdesc = np.zeros(0, wire.TEXDESC); d.texdata = np.zeros(0, np.uint8)
+    nt = d.tris.size
+    P = np.stack([np.stack([d.tris[v]["p"][k] for k in "xyz"], 1) for v in ("v0", "v1", "v2")], 1)   # (nt, 3, 3)
+    tmin, tmax = P.min(1), P.max(1)
+    nodes = np.zeros(2 * nt - 1, wire.NODE)
+    sufmin = np.minimum.accumulate(tmin[::-1], 0)[::-1]; sufmax = np.maximum.accumulate(tmax[::-1], 0)[::-1]
+    def setbox(n, mn, mx):
+        for k, a in enumerate("xyz"):
+            nodes[n]["bmin"][a] = mn[k]; nodes[n]["bmax"][a] = mx[k]
+    idx = 0
+    for t in range(nt - 1):                       # inner node idx: left = leaf(t) at idx+1, right = idx+2
+        setbox(idx, sufmin[t], sufmax[t]); nodes[idx]["parent"] = idx - 2 if t else -1; nodes[idx]["nPrims"] = 0
+        nodes[idx]["iStartOrRight"] = idx + 2
+        setbox(idx + 1, tmin[t], tmax[t]); nodes[idx + 1]["parent"] = idx; nodes[idx + 1]["nPrims"] = 1; nodes[idx + 1]["iStartOrRight"] = t
+        idx += 2
+    setbox(idx, tmin[nt - 1], tmax[nt - 1]); nodes[idx]["parent"] = idx - 2; nodes[idx]["nPrims"] = 1; nodes[idx]["iStartOrRight"] = nt - 1
+    d.nodes, d.indices = nodes, np.arange(nt, dtype=np.uint32)
+    d.world_radius = float(0.5 * np.linalg.norm(sufmax[0] - sufmin[0]))
+    p = common.scene_params(d, 32, 32, maxBounces=3)
+    g, o = _ctxs(d, p, 1024)
+    _free_run(g, o, 32 * 32, 6)
