@@ -38,7 +38,7 @@ def build_host(force=False):
     dep = src + glob.glob(os.path.join(PKG, "host", "*.hpp")) + _headers()
     out = os.path.join(PKG, "libfluctus_host.so")
     if force or _stale(out, dep):
-        _run(["g++"] + CXX_FLAGS + ["-fopenmp"] + src + ["-o", out, "-ldl"])
+        _run(["g++"] + CXX_FLAGS + ["-fopenmp"] + src + ["-o", out, "-ldl", "-lz"])
     return out
 
 

@@ -75,6 +75,16 @@ def generate_scene(kind, target_tris, seed):
         L.fh_scene_destroy(h)
 
 
+def load_png(path):
+    """RGBA8 texture, lower-left origin (row 0 = bottom scanline), as the reference's DevIL setup delivers it."""
+    L = lib()
+    w, h = C.c_uint32(), C.c_uint32()
+    _chk(L.fh_png_load(path.encode(), C.byref(w), C.byref(h), None))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    _chk(L.fh_png_load(path.encode(), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 BVH_MODES = {"sbvh": 0, "sah": 1, "binned": 2}
 
 

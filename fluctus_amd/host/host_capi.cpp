@@ -5,6 +5,7 @@
 #include "scene.hpp"
 #include "bvh.hpp"
 #include "envmap.hpp"
+#include "texture.hpp"
 #include <cstring>
 #include <string>
 #include <exception>
@@ -52,6 +53,15 @@ int fh_scene_set_tri_material(void *s, uint64_t first, uint64_t count, int matId
     FH_TRY
     auto &t = ((Scene *)s)->getTriangles();
     for (uint64_t i = first; i < first + count && i < t.size(); i++) t[i].matId = matId;
+    FH_CATCH
+}
+
+int fh_png_load(const char *path, uint32_t *w, uint32_t *h, uint8_t *rgba /* null: query size */)
+{
+    FH_TRY
+    Texture t = loadPNG(path);
+    *w = t.width; *h = t.height;
+    if (rgba) memcpy(rgba, t.rgba.data(), t.rgba.size());
     FH_CATCH
 }
 

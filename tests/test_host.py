@@ -198,3 +198,40 @@ def test_math_contract_accuracy():
         return s
     for s in (0, 1, 61, 2**32 - 1, 123456789):
         assert L.orc_hash(s) == h(s)
+
+
+@pytest.mark.parametrize("mode,bits", [("RGB", 8), ("RGBA", 8), ("L", 8), ("LA", 8), ("P", 8), ("I;16", 16)])
+def test_png_decoder_matches_pillow(tmp_path, mode, bits):
+    """PNG decode (zlib inflate + scanline filters) against Pillow for every supported colour type; origin lower-left."""
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    w, h = 37, 23                       # odd sizes exercise every filter type's edge handling
+    if mode == "I;16":
+        arr = rng.randint(0, 65536, (h, w)).astype(np.uint16)
+        im = Image.fromarray(arr, "I;16")
+        expect = np.stack([(arr >> 8).astype(np.uint8)] * 3 + [np.full((h, w), 255, np.uint8)], -1)
+    else:
+        base = (np.linspace(0, 255, w)[None, :, None] * np.ones((h, 1, 4)) + rng.randint(0, 40, (h, w, 4))).clip(0, 255).astype(np.uint8)
+        im = Image.fromarray(base, "RGBA").convert(mode)
+        expect = np.asarray(im.convert("RGBA"))
+    path = str(tmp_path / f"t_{mode.replace(';', '')}.png")
+    im.save(path)
+    got = host.load_png(path)
+    assert got.shape == (h, w, 4) and np.array_equal(got, expect[::-1])
+
+
+def test_png_decoder_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.png"
+    p.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\x00" * 64)
+    with pytest.raises(RuntimeError):
+        host.load_png(str(p))
+
+
+@needs_ref_assets
+def test_obj_loader_resolves_png_textures():
+    d = host.load_scene(REF + "/egyptcat/egyptcat.obj")
+    assert d.texdesc.size == 1 and tuple(d.texdesc[0]) == (0, 1024, 1024) and d.texdata.size == 1024 * 1024 * 4
+    assert d.materials[1]["map_Kd"] == 0 and d.materials[2]["map_Kd"] == -1        # `map_Kd EgyptCat.png` on material egyptcat
+    from PIL import Image
+    ref = np.asarray(Image.open(REF + "/egyptcat/EgyptCat.png").convert("RGBA"))[::-1]
+    assert np.array_equal(d.texdata.reshape(1024, 1024, 4), ref)

@@ -129,3 +129,22 @@ def test_first_frame_preview_path():
         _step(a, b, f"r{r} shadow", lambda c: c.wf_shadow())
         for c in (a, b):
             c.clear_queues()
+
+
+def test_egyptcat_real_asset_textured_glossy():
+    """A real reference asset end to end through the loaders: egyptcat.obj + .mtl (`shader glossy`, Ns 100000) +
+    EgyptCat.png (1024^2 diffuse texture), area light, single material queue."""
+    d = host.load_scene(common.REF_ASSETS + "/egyptcat/egyptcat.obj")
+    host.build_bvh(d, "sbvh")
+    assert d.texdesc.size == 1
+    w, h, n = 64, 48, 4096
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    lo = np.array([d.nodes[0]["bmin"][k] for k in "xyz"]); hi = np.array([d.nodes[0]["bmax"][k] for k in "xyz"])
+    c = 0.5 * (lo + hi)
+    wire.look_at(p, c + np.array([0.0, 0.2, 1.4]) * d.world_radius, c)
+    al = p["areaLight"]
+    al["pos"]["x"], al["pos"]["y"], al["pos"]["z"] = c + np.array([1.2, 0.8, 0.3]) * d.world_radius
+    al["size"] = (0.4 * d.world_radius, 0.4 * d.world_radius)
+    p["maxBounces"] = 4
+    a, b = _pair(d, p, n)
+    _iterate(a, b, w * h, 8, rtol=1e-4, atol=1e-5, mat_rtol=2e-3)
