@@ -33,13 +33,25 @@ TARGET_TRIS, SCENE_SEED = 500000, 42
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_workload(width=WIDTH, height=HEIGHT):
+# The other BASELINE.json configs (parity-test cases; selectable for extra measurements, never the default line)
+WORKLOADS = {
+    # name: (generator, target triangles, seed, bvh, width, height, bounces, useEnvMap, useAreaLight, camera pos, target)
+    "kitchen": ("kitchen", TARGET_TRIS, SCENE_SEED, "sbvh", 1920, 1080, 8, 1, 0, (0.3, 1.5, 4.4), (0.0, 0.9, -0.5)),
+    "conference": ("conference", 330000, 43, "sbvh", 1920, 1080, 8, 0, 1, (0.0, 1.2, 2.6), (0.0, 0.2, 0.0)),
+    "courtyard-1440p": ("courtyard", 10000000, 44, "binned", 2560, 1440, 12, 1, 0, (0.0, 3.0, 17.0), (0.0, 2.0, 0.0)),
+    "courtyard-2160p": ("courtyard", 10000000, 44, "binned", 3840, 2160, 16, 1, 0, (0.0, 3.0, 17.0), (0.0, 2.0, 0.0)),
+}
+
+
+def build_workload(width=None, height=None, name="kitchen"):
     from fluctus_amd import host, wire
-    d = host.generate_scene("kitchen", TARGET_TRIS, SCENE_SEED)
-    host.build_bvh(d, "sbvh")
+    gen, tris, seed, bvh, w, h, bounces, use_env, use_area, cam, target = WORKLOADS[name]
+    width, height = width or w, height or h
+    d = host.generate_scene(gen, tris, seed)
+    host.build_bvh(d, bvh)
     p = wire.default_params(width, height, d.world_radius, d.tris.size)
-    wire.look_at(p, (0.3, 1.5, 4.4), (0.0, 0.9, -0.5), fov=60.0)
-    p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = BOUNCES, 1, 0, 1
+    wire.look_at(p, cam, target, fov=60.0)
+    p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = bounces, use_env, use_area, 1
     env = host.synthetic_sky(512, 256)
     return d, p, env
 
@@ -107,8 +119,9 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--workload", default="kitchen", choices=sorted(WORKLOADS))
     ap.add_argument("--num-tasks", type=int, default=NUM_TASKS)
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
@@ -132,7 +145,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from fluctus_amd import device, driver
-    d, p, env = build_workload(args.width, args.height)
+    d, p, env = build_workload(args.width, args.height, args.workload)
+    args.width, args.height = int(p["width"]), int(p["height"])
     ctx = device.HipContext(args.num_tasks, device_index=local_rank)
     ctx.set_option("xcd_remap", args.xcd_remap)
     ctx.set_option("trace_mode", args.trace_mode)
@@ -228,17 +242,17 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mrays/s (primary+shadow) at 1080p, 8 bounces",
+            "metric": "Mrays/s (primary+shadow) at 1080p, 8 bounces" if args.workload == "kitchen" else f"Mrays/s (primary+shadow), {args.workload}",
             "value": rays_total / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
-                                   "separate material queues",
-                       "width": args.width, "height": args.height, "max_bounces": BOUNCES, "triangles": int(d.tris.size),
-                       "bvh": "sbvh", "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks,
+            "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
+                                    "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
+                       "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks,
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},
