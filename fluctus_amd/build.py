@@ -72,4 +72,13 @@ def build_hip(force=False):
 
 
 def build_all(force=False):
-    return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]
+    """Build whatever is stale.  Serialised with a file lock: with `torch.distributed.run` every rank calls this at start-up."""
+    import fcntl
+    if os.environ.get("FLX_NO_BUILD") == "1":
+        return []
+    with open(os.path.join(PKG, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)

@@ -97,6 +97,31 @@ __device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v
 __device__ __forceinline__ float4 mk4u(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 __device__ __forceinline__ f3 V(const flx_vec3 &v) { return mk3(v.x, v.y, v.z); }
 
+// Path-state accessors.  Every kernel streams the state exactly once per launch, while the BVH is re-read constantly;
+// FLX_NT marks state loads (bit 0) / stores (bit 1) non-temporal so they do not evict the tree from L2 / Infinity Cache.
+#ifndef FLX_NT
+#define FLX_NT 0
+#endif
+typedef float flx_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 rd4(const float4 *p)
+{
+#if FLX_NT & 1
+    flx_v4f v = __builtin_nontemporal_load(reinterpret_cast<const flx_v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void wr4(float4 *p, float4 v)
+{
+#if FLX_NT & 2
+    flx_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<flx_v4f *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // wave64 helpers
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)

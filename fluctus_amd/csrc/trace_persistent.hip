@@ -83,10 +83,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_persiste
                     }
                 }
                 const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(&st.rec[S_HITN][gid])[3]) & 2u;
-                st.rec[S_DIR][gid] = mk4u(dir, __float_as_uint(dirw) + 1u);
-                st.rec[S_HITP][gid] = mk4(P, t);
-                st.rec[S_HITN][gid] = mk4u(N, flags | keep);
-                st.rec[S_HITUV][gid] = make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId));
+                wr4(st.rec[S_DIR] + gid, mk4u(dir, __float_as_uint(dirw) + 1u));
+                wr4(st.rec[S_HITP] + gid, mk4(P, t));
+                wr4(st.rec[S_HITN] + gid, mk4u(N, flags | keep));
+                wr4(st.rec[S_HITUV] + gid, make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
             } else {
                 st.blocked[gid] = occluded ? 1u : 0u;
             }
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_persiste
             if (want && off < shardLen && idx < qlen) {
                 gid = queue[idx];
                 float4 o4, d4;
-                if (!ANY_HIT) { o4 = st.rec[S_ORIG][gid]; d4 = st.rec[S_DIR][gid]; }
-                else { o4 = st.rec[S_SHO][gid]; d4 = st.rec[S_SHD][gid]; }
+                if (!ANY_HIT) { o4 = rd4(st.rec[S_ORIG] + gid); d4 = rd4(st.rec[S_DIR] + gid); }
+                else { o4 = rd4(st.rec[S_SHO] + gid); d4 = rd4(st.rec[S_SHD] + gid); }
                 orig = ld3(o4); dir = ld3(d4); dirw = d4.w;
                 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                 tbest = ANY_HIT ? o4.w : FLX_FLT_MAX;
