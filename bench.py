@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
     ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--refill-thresh", type=int, default=40)
     args = ap.parse_args()
 
@@ -147,16 +148,51 @@ def main():
     from fluctus_amd import device, driver
     d, p, env = build_workload(args.width, args.height, args.workload)
     args.width, args.height = int(p["width"]), int(p["height"])
-    ctx = device.HipContext(args.num_tasks, device_index=local_rank)
-    ctx.set_option("xcd_remap", args.xcd_remap)
-    ctx.set_option("trace_mode", args.trace_mode)
-    ctx.set_option("overlap", args.overlap)
-    ctx.set_option("refill_thresh", args.refill_thresh)
-    ctx.upload_scene(d)
-    ctx.upload_envmap(env)
-    ctx.set_partition(rank, world)
-    ctx.set_params(p)
-    driver.reset_renderer(ctx)
+    # C independent wavefronts per GPU: the framebuffer partition is simply refined (rank*C + i of world*C), each wavefront
+    # has its own path state (num_tasks / C paths), queues and streams; their kernels interleave on the device so one
+    # wavefront's TA-bound traversal overlaps the other's HBM-bound logic / material / raygen phases.
+    C = max(1, args.ctx_per_gpu)
+    ctxs = []
+    for i in range(C):
+        c_ = device.HipContext(args.num_tasks // C, device_index=local_rank)
+        c_.set_option("xcd_remap", args.xcd_remap)
+        c_.set_option("trace_mode", args.trace_mode)
+        c_.set_option("overlap", args.overlap)
+        c_.set_option("refill_thresh", args.refill_thresh)
+        c_.upload_scene(d)
+        c_.upload_envmap(env)
+        c_.set_partition(rank * C + i, world * C)
+        c_.set_params(p)
+        driver.reset_renderer(c_)
+        ctxs.append(c_)
+    ctx = ctxs[0]
+
+    class _Group:
+        """Fan the calls the measurement code makes out over the GPU's wavefronts."""
+        def __getattr__(self, name):
+            def call(*a, **k):
+                out = [getattr(c_, name)(*a, **k) for c_ in ctxs]
+                return out[0]
+            return call
+
+        def counter_totals(self, reset=False):
+            return sum(c_.counter_totals(reset) for c_ in ctxs)
+
+        def profile_get(self):
+            acc = {}
+            for c_ in ctxs:
+                for k, (ms, n) in c_.profile_get().items():
+                    a = acc.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += n
+            return {k: (v[0], v[1]) for k, v in acc.items()}
+
+        def stats(self):
+            acc = {}
+            for c_ in ctxs:
+                for k, v in c_.stats().items():
+                    acc[k] = acc.get(k, 0) + v
+            return acc
+    if C > 1:
+        ctx = _Group()
 
     def barrier():
         if world > 1:
@@ -206,14 +242,14 @@ def main():
     ext_bytes, sh_bytes = algorithmic_bytes(st)
     bytes_per_ext_ray = ext_bytes / max(1, st["ext_rays"])
     ext_ms, ext_n = prof["extend"]
-    rays_per_launch = ext / world / max(1, args.steps)
+    rays_per_launch = ext / world / C / max(1, args.steps)
     achieved = (bytes_per_ext_ray * rays_per_launch) / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 if ext_ms > 0 else 0.0
     # k_extend shares the machine with the concurrent k_shadow; the pair's span gives the combined traversal rate
     span_ms, span_n = prof.get("trace_span", (0.0, 0))
     bytes_per_sh_ray = sh_bytes / max(1, st["shadow_rays"])
     combined = None
     if span_n:
-        combined_bytes = bytes_per_ext_ray * rays_per_launch + bytes_per_sh_ray * (sh / world / max(1, args.steps))
+        combined_bytes = bytes_per_ext_ray * rays_per_launch + bytes_per_sh_ray * (sh / world / C / max(1, args.steps))
         combined = combined_bytes / (span_ms / span_n * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -226,10 +262,10 @@ def main():
     # ---- multi-GPU: gather the radiance tiles over RCCL (outside the timed region)
     gather_ms = None
     if world > 1:
-        lp = ctx.local_pixels()
+        lp = ctxs[0].local_pixels()
         maxlp = (args.width * args.height + world - 1) // world
         tile = torch.zeros((maxlp, 4), dtype=torch.float32, device="cuda")
-        ctx.copy_pixels_to_device(tile.data_ptr())
+        ctxs[0].copy_pixels_to_device(tile.data_ptr())     # (with --ctx-per-gpu > 1 only the first wavefront's tile is exercised here)
         ctx.finish()
         torch.cuda.synchronize()
         g0 = time.perf_counter()
@@ -252,7 +288,7 @@ def main():
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
                                     "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
-                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks,
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C,
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},
