@@ -25,6 +25,16 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
 KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7}
 
 
+def _preload_torch_runtime():
+    """PyTorch-ROCm bundles its own libamdhip64 / HSA runtime.  If libfluctus_hip.so (linked against /opt/rocm) is loaded
+    first and torch later, the process ends up with two HSA runtimes and the first one no longer sees the GPU
+    (scripts/order_probe.sh).  Importing torch first makes both share one runtime; without torch nothing is needed."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib_path():
     # FLX_HIP_LIB selects an A/B build of the same library (scripts/build_variants.py); default = the shipped one
     return os.environ.get("FLX_HIP_LIB") or os.path.join(_HERE, "libfluctus_hip.so")
@@ -33,6 +43,7 @@ def lib_path():
 def lib():
     global _lib
     if _lib is None:
+        _preload_torch_runtime()
         path = lib_path()
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing -- the HIP extension is required (no fallback); run __graft_entry__.build()")

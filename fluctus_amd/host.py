@@ -11,6 +11,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        try:                              # see device._preload_torch_runtime: the C++ HipContext dlopens libfluctus_hip.so later
+            import torch  # noqa: F401
+        except Exception:
+            pass
         path = os.path.join(_HERE, "libfluctus_host.so")
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing -- run `python -c 'import __graft_entry__ as g; g.build()'`")
