@@ -19,6 +19,9 @@ namespace flxd {
 #define TOP_NODES 0              // >0: cache the first TOP_NODES inner nodes (BFS order) in LDS per block.  Measured SLOWER on MI355X
                                  // (top levels already hit the 32 KiB L1; the LDS copy costs occupancy) -- kept as an A/B switch, default off
 #endif
+#ifndef TRACE_UNIFORM_NODE
+#define TRACE_UNIFORM_NODE 0      // 1: scalar-load the node when every active lane of the wave is on the same one
+#endif
 #define MAX_LEVELS 64
 
 struct TraceAux {

@@ -43,8 +43,19 @@ __device__ __forceinline__ bool traverse(const Scene &sc, const float4 *s_top, u
                 if (top) { const float4 *np = s_top + cur * 4u; l0 = np[0]; l1 = np[1]; l2 = np[2]; l3 = np[3]; }
                 n0 = top ? l0 : g0; n1 = top ? l1 : g1; n2 = top ? l2 : g2; n3 = top ? l3 : g3;
             } else {
-                const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
-                n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+#if TRACE_UNIFORM_NODE
+                // all active lanes on the same node (the root always, the next levels for coherent rays): one scalar
+                // 64-byte load through the constant cache instead of 4 vector loads per lane through the TA
+                const uint32_t first = __builtin_amdgcn_readfirstlane(cur);
+                if (__ballot(cur == first) == __ballot(true)) {
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + first);
+                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+                } else
+#endif
+                {
+                    const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
+                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+                }
             }
             if (STATS) nInner++;
             float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
