@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
     ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--compact-nodes", type=int, default=1)
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--refill-thresh", type=int, default=40)
     args = ap.parse_args()
@@ -158,6 +159,7 @@ def main():
         c_.set_option("xcd_remap", args.xcd_remap)
         c_.set_option("trace_mode", args.trace_mode)
         c_.set_option("overlap", args.overlap)
+        c_.set_option("compact_nodes", args.compact_nodes)
         c_.set_option("refill_thresh", args.refill_thresh)
         c_.upload_scene(d)
         c_.upload_envmap(env)

@@ -54,6 +54,7 @@ struct flx_ctx {
     unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
     bool statsOn = false;
     int xcdRemap = 0;           // 1: each XCD gets a contiguous eighth of the queue (measured slower: round-robin keeps all XCDs on the same part of the tree)
+    int compact = 1;            // use the 32-byte compact node records when the tree allows it
     int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
     int refillThresh = 40;
     int numCUs = 256;
@@ -226,27 +227,9 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         trirecs[s].c = make_float4(t.v2.p.x, t.v2.p.y, t.v2.p.z, 0.0f);
     }
     // 2. inner-node records: both child boxes + refs; DFS numbering of inner nodes only
-    // Numbering: the top of the tree first, in BFS order (these records are cached in LDS by the trace kernels), then the
-    // remaining inner nodes in the reference's DFS order (subtrees stay contiguous for the caches).
     std::vector<int32_t> innerId(nnodes, -1);
-    uint32_t ninner = 0, topCount = 0;
-    {
-        const uint32_t TOP_MAX = 1023;
-        std::vector<uint32_t> frontier, next;
-        if (nodes[0].nPrims == 0) frontier.push_back(0);
-        while (!frontier.empty() && ninner + frontier.size() <= TOP_MAX) {
-            next.clear();
-            for (uint32_t ni : frontier) {
-                innerId[ni] = (int32_t)ninner++;
-                uint32_t l = ni + 1, r = nodes[ni].iStartOrRight;
-                if (l < nnodes && nodes[l].nPrims == 0) next.push_back(l);
-                if (r < nnodes && nodes[r].nPrims == 0) next.push_back(r);
-            }
-            frontier.swap(next);
-        }
-        topCount = ninner;
-        for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0 && innerId[i] < 0) innerId[i] = (int32_t)ninner++;
-    }
+    uint32_t ninner = 0;
+    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) innerId[i] = (int32_t)ninner++;    // reference DFS order
     auto childRef = [&](uint32_t ni, bool &ok) -> uint32_t {
         if (ni >= nnodes) { ok = false; return 0; }
         const flx_node &n = nodes[ni];
@@ -278,6 +261,33 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         }
     }
     NEED(c, ok, "flx_upload_scene: malformed node array");
+    // 2b. compact 32-byte records (see flx_device.h / trace.hip): valid only if, on every face of every inner node, at
+    // least one child carries the node's own plane bit for bit -- true for any BVH whose boxes are exact unions.
+    std::vector<CNode> cnodes;
+    {
+        bool compactable = ninner > 0 && ninner <= CREF_INDEX_MASK && nidx <= CREF_INDEX_MASK;
+        if (compactable) cnodes.resize(ninner);
+        for (size_t i = 0; i < nnodes && compactable; i++) {
+            if (nodes[i].nPrims != 0) continue;
+            const flx_node &P = nodes[i], &L = nodes[i + 1], &R = nodes[nodes[i].iStartOrRight];
+            const float pp[6] = {P.bmin.x, P.bmin.y, P.bmin.z, P.bmax.x, P.bmax.y, P.bmax.z};
+            const float lp[6] = {L.bmin.x, L.bmin.y, L.bmin.z, L.bmax.x, L.bmax.y, L.bmax.z};
+            const float rp[6] = {R.bmin.x, R.bmin.y, R.bmin.z, R.bmax.x, R.bmax.y, R.bmax.z};
+            const BNode &b = bnodes[innerId[i]];
+            CNode &cn = cnodes[innerId[i]];
+            uint32_t lf = 0, rf = 0;
+            for (int f = 0; f < 6; f++) {
+                const bool lo = memcmp(&lp[f], &pp[f], 4) == 0, ro = memcmp(&rp[f], &pp[f], 4) == 0;
+                if (!lo && !ro) { compactable = false; break; }
+                if (lo) lf |= 1u << (CREF_FLAG_SHIFT + f);
+                if (ro) rf |= 1u << (CREF_FLAG_SHIFT + f);
+                cn.inner[f] = lo ? rp[f] : lp[f];           // the non-owner's plane (either one when both own it)
+            }
+            cn.left = (b.left & FLX_LEAF_BIT) | lf | (b.left & CREF_INDEX_MASK);
+            cn.right = (b.right & FLX_LEAF_BIT) | rf | (b.right & CREF_INDEX_MASK);
+        }
+        if (!compactable) cnodes.clear();
+    }
     // 3. shading records per ORIGINAL triangle index
     std::vector<ShadeRec> shade(ntris);
     for (size_t i = 0; i < ntris; i++) {
@@ -291,10 +301,12 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     freeAll(c->sceneAllocs);
+    CNode *dC = nullptr;
     BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX;
     if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size()) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
         dalloc(c, c->sceneAllocs, &dTri, ntris) || dalloc(c, c->sceneAllocs, &dM, nmat) || dalloc(c, c->sceneAllocs, &dD, ntex) || dalloc(c, c->sceneAllocs, &dX, texbytes + 4))
         return 1;
+    if (!cnodes.empty()) { if (dalloc(c, c->sceneAllocs, &dC, cnodes.size())) return 1; HIPCHK(c, hipMemcpy(dC, cnodes.data(), cnodes.size() * sizeof(CNode), hipMemcpyHostToDevice)); }
     HIPCHK(c, hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dS, shade.data(), shade.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
@@ -302,9 +314,9 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     HIPCHK(c, hipMemcpy(dM, materials, nmat * sizeof(flx_material), hipMemcpyHostToDevice));
     if (ntex) HIPCHK(c, hipMemcpy(dD, texdesc, ntex * sizeof(flx_texdesc), hipMemcpyHostToDevice));
     if (texbytes) HIPCHK(c, hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
+    c->sc.cnodes = c->compact ? dC : nullptr; c->sc.cnodesAll = dC;
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
-    c->sc.topCount = topCount;
     return 0;
 }
 
@@ -541,6 +553,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && (value == 0 || value == 1)) { c->overlap = value; return 0; }
+    if (name && strcmp(name, "compact_nodes") == 0 && (value == 0 || value == 1)) { c->compact = value; c->sc.cnodes = value ? c->sc.cnodesAll : nullptr; return 0; }
     if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 1)) { c->traceMode = value; return 0; }
     if (name && strcmp(name, "refill_thresh") == 0 && value >= 1 && value <= 64) { c->refillThresh = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");

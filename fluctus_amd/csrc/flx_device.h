@@ -54,6 +54,15 @@ struct BNode {                    // 64 B, 64-B aligned
     uint32_t pad[2];
 };
 
+// Compact inner-node record (32 B), usable when the node's own box is known (see trace.hip): per face the plane of
+// the child that does NOT share the parent's plane; child references carry 6 ownership bits each.
+#define CREF_FLAG_SHIFT 25
+#define CREF_INDEX_MASK 0x01FFFFFFu               // 25-bit BNode index / triangle slot (33 M)
+struct CNode {
+    float inner[6];               // minx, miny, minz, maxx, maxy, maxz of the non-owning child
+    uint32_t left, right;         // FLX_LEAF_BIT | ownership bits << 25 | index
+};
+
 struct TriRec {                   // 48 B: three float4
     float4 a;                     // v0.xyz, triangle index (int bits)
     float4 b;                     // v1.xyz, leaf count in the first record of a leaf run (int bits)
@@ -69,6 +78,8 @@ struct ShadeRec {                 // 64 B: four float4
 
 struct Scene {
     const BNode *bnodes;
+    const CNode *cnodes;          // nullptr when the tree is not compactable (a child box not inside-touching its parent) or switched off
+    const CNode *cnodesAll;       // the uploaded array (option compact_nodes toggles cnodes)
     const TriRec *trirecs;
     const ShadeRec *shade;
     const flx_triangle *tris;     // reference-layout triangles (tangent frames for normal maps only)
@@ -76,7 +87,6 @@ struct Scene {
     const flx_texdesc *texdesc;
     const uint8_t *texdata;
     uint32_t rootRef;             // BNode 0 (inner) -- tiny scenes get a synthetic root
-    uint32_t topCount;            // BNodes [0, topCount) are the top of the tree in BFS order (LDS-cacheable)
     // environment map
     const float4 *envRGBA;
     const float *probTable, *pdfTable;

@@ -15,12 +15,9 @@ namespace flxd {
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1        // __launch_bounds__ 2nd argument (min waves per SIMD -> VGPR cap)
 #endif
-#ifndef TOP_NODES
-#define TOP_NODES 0              // >0: cache the first TOP_NODES inner nodes (BFS order) in LDS per block.  Measured SLOWER on MI355X
-                                 // (top levels already hit the 32 KiB L1; the LDS copy costs occupancy) -- kept as an A/B switch, default off
-#endif
-#ifndef TRACE_UNIFORM_NODE
-#define TRACE_UNIFORM_NODE 0      // 1: scalar-load the node when every active lane of the wave is on the same one
+#ifndef TRACE_COMPACT
+#define TRACE_COMPACT 0           // 1: lossless 32-byte compact node records for nodes entered straight from their parent (2 loads instead
+                                 // of 4).  Bit-exact, but measured 5 % SLOWER (78 VGPRs -> 6 waves/SIMD, decode ALU, two load paths); A/B only
 #endif
 #define MAX_LEVELS 64
 

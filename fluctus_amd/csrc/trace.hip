@@ -10,9 +10,8 @@
 //  * the traversal stack lives in LDS, laid out [level][lane] so a wave's push/pop is one
 //    conflict-free ds_write_b32/ds_read_b32 (the reference's `uint stack[64]` is private memory,
 //    i.e. scratch on a wave64 machine); levels >= LDS_LEVELS spill to a global side buffer;
-//  * the top of the tree (the first TOP_NODES inner nodes in BFS order, visited by every ray) is copied into LDS by
-//    each block and read from there: ~half of all node visits never reach the L1/L2 gather path, which is what bounds
-//    this kernel (scripts/ubench/gather_sweep.hip: random 64-B gathers run at 55-200 G records/s depending on cache level);
+//  * optional (-DTRACE_COMPACT=1, measured slower, off): a node entered straight from its parent can be read from a
+//    lossless 32-byte compact record (2 loads instead of 4); only popped nodes and the root need the full record;
 //  * the current node is kept in a register ("push farther, continue with closer"), which is the
 //    same visit order as the reference's push-both-pop-one;
 //  * triangles are 48-B position-only records in leaf order; normals/uvs/matId are fetched once
@@ -25,53 +24,73 @@
 namespace flxd {
 
 template <bool ANY_HIT, bool STATS>
-__device__ __forceinline__ bool traverse(const Scene &sc, const float4 *s_top, uint32_t topCount, Stack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
+__device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
                                          int &tribest, uint32_t &nInner, uint32_t &nTri)
 {
     const f3 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     int sp = 0;
     uint32_t cur = sc.rootRef;
+#if TRACE_COMPACT
+    bool boxKnown = false;
+    float pmin[3] = {0.0f, 0.0f, 0.0f}, pmax[3] = {0.0f, 0.0f, 0.0f};
+#endif
     for (;;) {
         if (!(cur & FLX_LEAF_BIT)) {
-            float4 n0, n1, n2, n3;
-            if (TOP_NODES > 0) {
-                // top of the tree from LDS (4 x ds_read_b128), the rest from memory; both groups of loads are issued
-                // before either result is used so their latencies overlap in a wave that has lanes of both kinds
-                const bool top = cur < topCount;
-                float4 g0, g1, g2, g3, l0, l1, l2, l3;
-                if (!top) { const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur); g0 = np[0]; g1 = np[1]; g2 = np[2]; g3 = np[3]; }
-                if (top) { const float4 *np = s_top + cur * 4u; l0 = np[0]; l1 = np[1]; l2 = np[2]; l3 = np[3]; }
-                n0 = top ? l0 : g0; n1 = top ? l1 : g1; n2 = top ? l2 : g2; n3 = top ? l3 : g3;
-            } else {
-#if TRACE_UNIFORM_NODE
-                // all active lanes on the same node (the root always, the next levels for coherent rays): one scalar
-                // 64-byte load through the constant cache instead of 4 vector loads per lane through the TA
-                const uint32_t first = __builtin_amdgcn_readfirstlane(cur);
-                if (__ballot(cur == first) == __ballot(true)) {
-                    const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + first);
-                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
-                } else
-#endif
-                {
-                    const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
-                    n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+            float lmin[3], lmax[3], rmin[3], rmax[3];
+            uint32_t left, right;
+#if TRACE_COMPACT
+            if (boxKnown) {
+                // Reached straight from the parent, whose test just produced this node's own box (pmin, pmax): a 32-byte
+                // record suffices.  The union of the two child boxes IS the parent box, so on every one of the six faces at
+                // least one child carries the parent's plane; the record stores only the other child's plane per face plus
+                // two ownership bits (in the spare high bits of the child references).  Lossless: the 12 decoded floats are
+                // bit-identical to the full record's, 2 vector loads instead of 4.
+                const float4 *cp = reinterpret_cast<const float4 *>(sc.cnodes + cur);
+                const float4 c0 = cp[0], c1 = cp[1];
+                const uint32_t lr = __float_as_uint(c1.z), rr = __float_as_uint(c1.w);
+                const float in[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
+                const float par[6] = {pmin[0], pmin[1], pmin[2], pmax[0], pmax[1], pmax[2]};
+                float lp[6], rp[6];
+#pragma unroll
+                for (int f = 0; f < 6; f++) {
+                    lp[f] = (lr & (1u << (CREF_FLAG_SHIFT + f))) ? par[f] : in[f];
+                    rp[f] = (rr & (1u << (CREF_FLAG_SHIFT + f))) ? par[f] : in[f];
                 }
+                lmin[0] = lp[0]; lmin[1] = lp[1]; lmin[2] = lp[2]; lmax[0] = lp[3]; lmax[1] = lp[4]; lmax[2] = lp[5];
+                rmin[0] = rp[0]; rmin[1] = rp[1]; rmin[2] = rp[2]; rmax[0] = rp[3]; rmax[1] = rp[4]; rmax[2] = rp[5];
+                left = (lr & FLX_LEAF_BIT) | (lr & CREF_INDEX_MASK); right = (rr & FLX_LEAF_BIT) | (rr & CREF_INDEX_MASK);
+            } else
+#endif
+            {
+                const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                lmin[0] = n0.x; lmin[1] = n0.y; lmin[2] = n0.z; lmax[0] = n0.w; lmax[1] = n1.x; lmax[2] = n1.y;
+                rmin[0] = n1.z; rmin[1] = n1.w; rmin[2] = n2.x; rmax[0] = n2.y; rmax[1] = n2.z; rmax[2] = n2.w;
+                left = __float_as_uint(n3.x); right = __float_as_uint(n3.y);
             }
             if (STATS) nInner++;
-            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-            uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
             float lnear, rnear;
             bool lh = slab(lmin, lmax, orig, dinv, tbest, &lnear);
             bool rh = slab(rmin, rmax, orig, dinv, tbest, &rnear);
             if (lh && rh) {
                 uint32_t closer = left, farther = right;
-                if (rnear < lnear) { closer = right; farther = left; }
+                bool goRight = rnear < lnear;
+                if (goRight) { closer = right; farther = left; }
                 stk.push(sp++, farther);
                 cur = closer;
+#if TRACE_COMPACT
+                for (int k = 0; k < 3; k++) { pmin[k] = goRight ? rmin[k] : lmin[k]; pmax[k] = goRight ? rmax[k] : lmax[k]; }
+                boxKnown = sc.cnodes != nullptr;
+#endif
                 continue;
-            } else if (lh) { cur = left; continue; }
-            else if (rh) { cur = right; continue; }
+            } else if (lh || rh) {
+                cur = lh ? left : right;
+#if TRACE_COMPACT
+                for (int k = 0; k < 3; k++) { pmin[k] = lh ? lmin[k] : rmin[k]; pmax[k] = lh ? lmax[k] : rmax[k]; }
+                boxKnown = sc.cnodes != nullptr;
+#endif
+                continue;
+            }
         } else {
             uint32_t slot = cur & ~FLX_LEAF_BIT;
             const float4 *tp = reinterpret_cast<const float4 *>(sc.trirecs + slot);
@@ -91,6 +110,9 @@ __device__ __forceinline__ bool traverse(const Scene &sc, const float4 *s_top, u
         }
         if (sp == 0) break;
         cur = stk.pop(--sp);
+#if TRACE_COMPACT
+        boxKnown = false;                      // a popped node's own box is not at hand: full record
+#endif
     }
     return false;
 }
@@ -99,13 +121,6 @@ template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
-    __shared__ float4 s_top[(TOP_NODES > 0 ? TOP_NODES : 1) * 4];
-    const uint32_t topCount = sc.topCount < (uint32_t)TOP_NODES ? sc.topCount : (uint32_t)TOP_NODES;
-    if (TOP_NODES > 0) {                                          // every thread of the block helps, including those without a ray
-        const float4 *src = reinterpret_cast<const float4 *>(sc.bnodes);
-        for (uint32_t i = threadIdx.x; i < topCount * 4u; i += TRACE_BLOCK) s_top[i] = src[i];
-        __syncthreads();
-    }
     const uint32_t qlen = qs.counters[FLX_Q_EXTENSION];
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, xcdRemap);
     const uint32_t idx = blk * TRACE_BLOCK + threadIdx.x;
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     float t = FLX_FLT_MAX, u = 0.0f, v = 0.0f;
     int tri = -1;
     uint32_t nInner = 0, nTri = 0;
-    traverse<false, STATS>(sc, s_top, topCount, stk, orig, dir, t, u, v, tri, nInner, nTri);
+    traverse<false, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
 
     // commit: shading attributes of the winning triangle (reference: src/bvh.cl:271-279)
     f3 P = mk3(0.0f), N = mk3(0.0f);
@@ -172,13 +187,6 @@ template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_shadow(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
-    __shared__ float4 s_top[(TOP_NODES > 0 ? TOP_NODES : 1) * 4];
-    const uint32_t topCount = sc.topCount < (uint32_t)TOP_NODES ? sc.topCount : (uint32_t)TOP_NODES;
-    if (TOP_NODES > 0) {                                          // every thread of the block helps, including those without a ray
-        const float4 *src = reinterpret_cast<const float4 *>(sc.bnodes);
-        for (uint32_t i = threadIdx.x; i < topCount * 4u; i += TRACE_BLOCK) s_top[i] = src[i];
-        __syncthreads();
-    }
     const uint32_t qlen = qs.counters[FLX_Q_SHADOW];
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, xcdRemap);
     const uint32_t idx = blk * TRACE_BLOCK + threadIdx.x;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_shadow(State s
     if (p.useAreaLight) { float tl = lenL; occluded = light_quad(p.areaLight, orig, dir, &tl); }
     if (!occluded) {
         float t = lenL, u, v; int tri;
-        occluded = traverse<true, STATS>(sc, s_top, topCount, stk, orig, dir, t, u, v, tri, nInner, nTri);
+        occluded = traverse<true, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
     }
     st.blocked[gid] = occluded ? 1u : 0u;
 
