@@ -19,6 +19,9 @@ namespace flxd {
 #define TRACE_COMPACT 0           // 1: lossless 32-byte compact node records for nodes entered straight from their parent (2 loads instead
                                  // of 4).  Bit-exact, but measured 5 % SLOWER (78 VGPRs -> 6 waves/SIMD, decode ALU, two load paths); A/B only
 #endif
+#ifndef SHADOW_MIN_WAVES
+#define SHADOW_MIN_WAVES 1         // 8 fits (64 VGPRs, no spill) but measures the same as 7
+#endif
 #define MAX_LEVELS 64
 
 struct TraceAux {

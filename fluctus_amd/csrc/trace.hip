@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_shadow(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
+__global__ __launch_bounds__(TRACE_BLOCK, SHADOW_MIN_WAVES) void k_shadow(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
     const uint32_t qlen = qs.counters[FLX_Q_SHADOW];
