@@ -100,6 +100,18 @@ class OracleContext:
     def wf_logic(self, first=False): self.L.orc_wf_logic(self.h, int(bool(first)))
     def wf_materials(self): self.L.orc_wf_materials(self.h)
     def postprocess(self): self.L.orc_postprocess(self.h)
+    # microkernel integrator
+    def mk_reset(self): self.L.orc_mk_reset(self.h)
+    def mk_raygen(self): self.L.orc_mk_raygen(self.h)
+    def mk_next_vertex(self): self.L.orc_mk_next_vertex(self.h)
+    def mk_sample_bsdf(self): self.L.orc_mk_sample_bsdf(self.h)
+    def mk_splat(self): self.L.orc_mk_splat(self.h)
+    def mk_splat_preview(self): self.L.orc_mk_splat_preview(self.h)
+
+    def mk_stats(self, reset=False):
+        out = np.zeros(4, np.uint32)
+        self.L.orc_mk_stats(self.h, _p(out), int(reset))
+        return out
     def clear_queues(self): self.L.orc_clear_queues(self.h)
     def finish(self): pass
 

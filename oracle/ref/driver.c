@@ -43,6 +43,15 @@ void wavefrontGGXReflection(float *, void *, uint *, uint *, void *, uint8_t *, 
 void wavefrontGGXRefraction(float *, void *, uint *, uint *, void *, uint8_t *, void *, void *, uint);
 void wavefrontDelta(float *, void *, uint *, uint *, void *, uint8_t *, void *, void *, uint);
 void wavefrontAllMaterials(float *, void *, uint *, uint *, void *, uint8_t *, void *, void *, uint);
+/* microkernel integrator (argument lists: reference src/mk_*.cl) */
+void mk_reset(float *tasks, float *pixels, float *denAlbedo, float *denNormal, void *params, uint numTasks);
+void genCameraRays(float *tasks, void *params, uint numTasks);
+void nextVertex(float *tasks, void *materials, uint8_t *texData, void *textures, float *denNormal, void *tris, void *nodes, uint *indices, void *params,
+                void *stats, const ref_image *envMap, float *pdfTable, uint numTasks);
+void sampleBsdf(float *tasks, float *denAlbedo, void *materials, uint8_t *texData, void *textures, const ref_image *envMap, float *probTable, int *aliasTable,
+                float *pdfTable, void *tris, void *nodes, uint *indices, void *params, void *stats, uint numTasks);
+void splat(float *tasks, float *pixels, void *params, void *stats, uint numTasks);
+void splatPreview(float *tasks, float *pixels, void *params, uint numTasks);
 void process(float *pixelsRaw, float *denAlbedo, float *denNormal, float *pixelsPreview, float *denAlbedoGL, float *denNormalGL, void *params, uint numTasks);
 
 typedef struct {
@@ -57,6 +66,7 @@ typedef struct {
     void *tris; size_t ntris; uint *indices; size_t nidx; void *nodes; size_t nnodes;
     void *materials; size_t nmat; void *texdesc; size_t ntex; uint8_t *texdata; size_t texbytes;
     ref_image env; float *envRGBA; float *prob, *pdf; int *alias;
+    uint32_t mkStats[4] __attribute__((aligned(16)));
 } ref_ctx;
 
 static void *dup(const void *src, size_t bytes) { void *p = NULL; if (posix_memalign(&p, 64, bytes ? bytes : 64)) return NULL; if (src && bytes) memcpy(p, src, bytes); return p; }
@@ -179,3 +189,21 @@ int ref_state_export(ref_ctx *c, float *out) { memcpy(out, c->tasks, (size_t)FLX
 int ref_state_import(ref_ctx *c, const float *in) { memcpy(c->tasks, in, (size_t)FLX_NUM_COLS * c->numTasks * 4); return 0; }
 int ref_queue_read(ref_ctx *c, int q, uint32_t *out) { memcpy(out, c->queues[q], (size_t)c->numTasks * 4); return 0; }
 int ref_queue_write(ref_ctx *c, int q, const uint32_t *in, uint32_t n) { memcpy(c->queues[q], in, (size_t)n * 4); return 0; }
+
+/* ---- microkernel integrator: launch ranges of src/clcontext.cpp:709-750 (reset/splat: width x height; the rest: NUM_TASKS) */
+int ref_mk_reset(ref_ctx *c) { RANGE(c->npix, mk_reset(c->tasks, c->pixels, c->denAlbedo, c->denNormal, &c->params, c->numTasks)); return 0; }
+int ref_mk_raygen(ref_ctx *c) { RANGE(c->numTasks, genCameraRays(c->tasks, &c->params, c->numTasks)); return 0; }
+int ref_mk_next_vertex(ref_ctx *c)
+{
+    RANGE(c->numTasks, nextVertex(c->tasks, c->materials, c->texdata, c->texdesc, c->denNormal, c->tris, c->nodes, c->indices, &c->params, c->mkStats, &c->env, c->pdf, c->numTasks));
+    return 0;
+}
+int ref_mk_sample_bsdf(ref_ctx *c)
+{
+    RANGE(c->numTasks, sampleBsdf(c->tasks, c->denAlbedo, c->materials, c->texdata, c->texdesc, &c->env, c->prob, c->alias, c->pdf, c->tris, c->nodes, c->indices,
+                                  &c->params, c->mkStats, c->numTasks));
+    return 0;
+}
+int ref_mk_splat(ref_ctx *c) { RANGE(c->npix, splat(c->tasks, c->pixels, &c->params, c->mkStats, c->numTasks)); return 0; }
+int ref_mk_splat_preview(ref_ctx *c) { RANGE(c->npix, splatPreview(c->tasks, c->pixels, &c->params, c->numTasks)); return 0; }
+int ref_mk_stats(ref_ctx *c, uint32_t *out4, int reset) { memcpy(out4, c->mkStats, 16); if (reset) memset(c->mkStats, 0, 16); return 0; }

@@ -68,6 +68,7 @@ struct Ctx {
     uint64_t stat[6] = {0, 0, 0, 0, 0, 0}; /* ext: rays, inner, tri, hits; shadow: inner, tri */
     uint64_t statShadowRays = 0;
     int threads = 1;
+    uint32_t mkStats[4] = {0, 0, 0, 0};   /* RenderStats: primaryRays, extensionRays, shadowRays, samples (geom.h:254-260) */
 };
 
 /* --- SoA access (reference: geom.h:38-49) -------------------------------- */
@@ -1203,6 +1204,229 @@ void k_materials(Ctx &c)
     }
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* microkernel integrator (mk_*.cl) -- SURVEY 8(f) N3                         */
+/* one path per pixel, `phase` state machine (geom.h:183-192)                */
+/* ------------------------------------------------------------------------ */
+enum { MK_RT_NEXT_VERTEX = 0, MK_SAMPLE_BSDF = 1, MK_SPLAT_SAMPLE = 4, MK_GENERATE_CAMERA_RAY = 5 };
+
+uint32_t mkLimit(Ctx &c) { return std::min(c.params.width * c.params.height, c.numTasks); }
+
+/* reference: mk_reset.cl:3-43 */
+void k_mk_reset(Ctx &c)
+{
+    uint32_t limit = mkLimit(c);
+    for (uint32_t gid = 0; gid < limit; gid++) {
+        float *px = &c.pixels[(size_t)gid * 4]; px[0] = px[1] = px[2] = px[3] = 0.0f;
+        I(c, FLX_COL_PHASE, gid) = MK_GENERATE_CAMERA_RAY;
+        W3(c, FLX_COL_EI, gid, mk3(0.0f)); W3(c, FLX_COL_T, gid, mk3(1.0f));
+        U(c, FLX_COL_PATH_LEN, gid) = 0; U(c, FLX_COL_LAST_SPECULAR, gid) = 1; F(c, FLX_COL_LAST_PDF_W, gid) = 1.0f;
+        U(c, FLX_COL_FIRST_DIFFUSE, gid) = 0; U(c, FLX_COL_SEED, gid) = gid;
+    }
+}
+
+/* reference: mk_raygen.cl:4-63 */
+void k_mk_raygen(Ctx &c)
+{
+    const flx_render_params &p = c.params;
+    uint32_t limit = mkLimit(c);
+    for (uint32_t gid = 0; gid < limit; gid++) {
+        if (I(c, FLX_COL_PHASE, gid) != MK_GENERATE_CAMERA_RAY) continue;
+        uint32_t seed = U(c, FLX_COL_SEED, gid);
+        float x = (float)(gid % p.width), y = (float)(gid / p.width);
+        x += rand01(&seed); y += rand01(&seed);
+        float NDCx = x / (float)p.width, NDCy = y / (float)p.height;
+        float SCRx = 2.0f * NDCx - 1.0f, SCRy = 2.0f * NDCy - 1.0f;
+        SCRx *= (float)p.width / (float)p.height;
+        float scale = tanf_(0.5f * p.camera.fov * FLX_PI / 180.0f);
+        SCRx *= scale; SCRy *= scale;
+        f3 rayOrig = V(p.camera.pos);
+        f3 rayTarget = rayOrig + V(p.camera.right) * SCRx + V(p.camera.up) * SCRy + V(p.camera.dir);
+        f3 rayDirection = normalize(rayTarget - rayOrig);
+        f3 fp = V(p.camera.pos) + rayDirection * p.camera.focalDist;
+        f2 rnd = uniformSampleDisk(&seed);
+        rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
+        rayDirection = normalize(fp - rayOrig);
+        W3(c, FLX_COL_ORIG, gid, rayOrig); W3(c, FLX_COL_DIR, gid, rayDirection);
+        U(c, FLX_COL_SEED, gid) = seed;
+        I(c, FLX_COL_PHASE, gid) = MK_RT_NEXT_VERTEX;
+    }
+}
+
+/* reference: mk_next_vertex.cl:7-123 */
+void k_mk_next_vertex(Ctx &c)
+{
+    const flx_render_params &p = c.params;
+    uint32_t limit = mkLimit(c);
+    uint32_t prim = 0, ext = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : prim, ext) num_threads(c.threads)
+    for (int64_t g = 0; g < (int64_t)limit; g++) {
+        uint32_t gid = (uint32_t)g;
+        if (I(c, FLX_COL_PHASE, gid) != MK_RT_NEXT_VERTEX) continue;
+        f3 rayOrig = R3(c, FLX_COL_ORIG, gid), rayDir = R3(c, FLX_COL_DIR, gid);
+        Hit hit = emptyHit(FLX_FLT_MAX);
+        uint64_t a = 0, b = 0;
+        bvh_intersect(c, rayOrig, rayDir, &hit, &a, &b);
+        if (p.sampleImpl && p.useAreaLight) intersectLight(&hit, rayOrig, rayDir, p);
+        writeHit(c, gid, hit);
+        uint32_t len = U(c, FLX_COL_PATH_LEN, gid);
+        if (len == 0) prim++; else ext++;
+        len += 1;
+        U(c, FLX_COL_PATH_LEN, gid) = len;
+        if (hit.i < 0) {
+            f3 bg = mk3(0.0f);
+            if (p.useEnvMap && (len == 1 || p.sampleImpl)) bg = evalEnvMapDir(c, rayDir) * p.envMapStrength;
+            float weight = 1.0f;
+            bool lastSpecular = U(c, FLX_COL_LAST_SPECULAR, gid) != 0;
+            if (p.sampleImpl && p.sampleExpl && p.useEnvMap && len > 1 && !lastSpecular) {
+                const float lightPickProb = 1.0f;
+                float directPdfW = envMapPdf(c, rayDir);
+                float actualPdfW = F(c, FLX_COL_LAST_PDF_W, gid);
+                weight = (actualPdfW * lightPickProb) / (actualPdfW * lightPickProb + directPdfW);
+            }
+            f3 T = R3(c, FLX_COL_T, gid);
+            W3(c, FLX_COL_EI, gid, R3(c, FLX_COL_EI, gid) + weight * T * bg);
+            I(c, FLX_COL_PHASE, gid) = MK_SPLAT_SAMPLE;
+        } else if (hit.areaLightHit) {
+            float misWeight = 1.0f;
+            bool lastSpecular = U(c, FLX_COL_LAST_SPECULAR, gid) != 0;
+            if (p.sampleExpl && len > 1 && !lastSpecular) {
+                float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
+                float directPdfW = pdfAtoW(directPdfA, length(hit.P - rayOrig), dot(normalize(-rayDir), hit.N));
+                const float lightPickProb = 1.0f;
+                float lastPdfW = F(c, FLX_COL_LAST_PDF_W, gid);
+                misWeight = lastPdfW / (lastPdfW + directPdfW * lightPickProb);
+            }
+            f3 T = R3(c, FLX_COL_T, gid);
+            W3(c, FLX_COL_EI, gid, R3(c, FLX_COL_EI, gid) + T * misWeight * V(p.areaLight.E));
+            I(c, FLX_COL_PHASE, gid) = MK_SPLAT_SAMPLE;
+        } else {
+            I(c, FLX_COL_PHASE, gid) = MK_SAMPLE_BSDF;
+        }
+    }
+    c.mkStats[0] += prim; c.mkStats[1] += ext;
+}
+
+/* reference: mk_sample_bsdf.cl:8-197 */
+void k_mk_sample_bsdf(Ctx &c)
+{
+    const flx_render_params &p = c.params;
+    uint32_t limit = mkLimit(c);
+    uint32_t shadow = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : shadow) num_threads(c.threads)
+    for (int64_t g = 0; g < (int64_t)limit; g++) {
+        uint32_t gid = (uint32_t)g;
+        if (I(c, FLX_COL_PHASE, gid) != MK_SAMPLE_BSDF) continue;
+        uint32_t seed = U(c, FLX_COL_SEED, gid);
+        f3 rayDir = R3(c, FLX_COL_DIR, gid);
+        Hit hit = readHit(c, gid);
+        const flx_material &mat = c.materials[hit.matId];
+        hit.N = tangentSpaceNormal(c, hit, mat);
+        bool backface = dot(hit.N, rayDir) > 0.0f;
+        if (backface) hit.N = hit.N * -1.0f;
+        f3 orig = hit.P - 1e-3f * rayDir;
+        uint64_t a = 0, b = 0;
+        if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {
+            const float lightPickProb = 1.0f;
+            if (p.useEnvMap) {
+                f3 L; float directPdfW = 0.0f;
+                sampleEnvMapAlias(c, rand01(&seed), &L, &directPdfW);
+                float lenL = 2.0f * p.worldRadius;
+                L = normalize(L);
+                Hit hitL = emptyHit(lenL);
+                if (p.useAreaLight) intersectLight(&hitL, orig, L, p);
+                bool occluded = (hitL.i > -1) || bvh_occluded(c, orig, L, lenL, &a, &b);
+                shadow++;
+                if (!occluded && directPdfW != 0.0f) {
+                    f3 brdf = bxdfEval(c, hit, mat, backface, rayDir, L);
+                    float cosTh = fmaxf_(0.0f, dot(L, hit.N));
+                    float bsdfPdfW = fmaxf_(0.0f, bxdfPdf(c, hit, mat, backface, rayDir, L));
+                    float weight = 1.0f;
+                    if (p.sampleImpl) weight = (directPdfW * lightPickProb) / (directPdfW * lightPickProb + bsdfPdfW);
+                    f3 T = R3(c, FLX_COL_T, gid);
+                    f3 envMapLi = evalEnvMapDir(c, L) * p.envMapStrength;
+                    f3 contrib = brdf * T * envMapLi * weight * cosTh / (lightPickProb * directPdfW);
+                    W3(c, FLX_COL_EI, gid, R3(c, FLX_COL_EI, gid) + contrib);
+                }
+            }
+            if (p.useAreaLight) {
+                float directPdfA; f3 posL;
+                sampleAreaLight(p.areaLight, &directPdfA, &posL, &seed);
+                f3 L = posL - orig;
+                float lenL = length(L);
+                L = normalize(L);
+                bool occluded = bvh_occluded(c, orig, L, lenL, &a, &b);
+                shadow++;
+                float cosLight = fmaxf_(dot(V(p.areaLight.N), -L), 0.0f);
+                if (!occluded && cosLight > 0.0f) {
+                    f3 brdf = bxdfEval(c, hit, mat, backface, rayDir, L);
+                    float cosTh = fmaxf_(0.0f, dot(L, hit.N));
+                    float directPdfW = pdfAtoW(directPdfA, lenL, cosLight);
+                    float bsdfPdfW = fmaxf_(0.0f, bxdfPdf(c, hit, mat, backface, rayDir, L));
+                    float weight = 1.0f;
+                    if (p.sampleImpl) weight = (directPdfW * lightPickProb) / (directPdfW * lightPickProb + bsdfPdfW);
+                    f3 T = R3(c, FLX_COL_T, gid);
+                    f3 contrib = brdf * T * V(p.areaLight.E) * weight * cosTh / (lightPickProb * directPdfW);
+                    W3(c, FLX_COL_EI, gid, R3(c, FLX_COL_EI, gid) + contrib);
+                }
+            }
+        }
+        float contProb = 1.0f;
+        uint32_t len = U(c, FLX_COL_PATH_LEN, gid);
+        bool terminate = (len - 1 >= p.maxBounces);
+        if (terminate && p.useRoulette) {
+            contProb = clampf(luminance(R3(c, FLX_COL_T, gid)), 0.01f, 0.5f);
+            terminate = (rand01(&seed) > contProb);
+        }
+        float pdfW = 0.0f; f3 newDir = mk3(0.0f);   /* uninitialised in the reference; see sampleGlossy */
+        f3 bsdf = bxdfSample(c, hit, mat, backface, rayDir, &newDir, &pdfW, &seed);
+        float costh = dot(hit.N, normalize(newDir));
+        pdfW *= contProb;
+        if (pdfW == 0.0f || is_zero(bsdf)) terminate = true;
+        f3 newT = R3(c, FLX_COL_T, gid) * bsdf * costh / pdfW;
+        orig = hit.P + 1e-4f * newDir;
+        W3(c, FLX_COL_T, gid, newT); W3(c, FLX_COL_ORIG, gid, orig); W3(c, FLX_COL_DIR, gid, newDir);
+        F(c, FLX_COL_LAST_PDF_W, gid) = pdfW;
+        U(c, FLX_COL_SEED, gid) = seed;
+        U(c, FLX_COL_LAST_SPECULAR, gid) = FLX_BXDF_IS_SINGULAR(mat.type) ? 1u : 0u;
+        I(c, FLX_COL_PHASE, gid) = terminate ? MK_SPLAT_SAMPLE : MK_RT_NEXT_VERTEX;
+    }
+    c.mkStats[2] += shadow;
+}
+
+/* reference: mk_splat.cl:4-41 */
+void k_mk_splat(Ctx &c)
+{
+    uint32_t limit = mkLimit(c);
+    for (uint32_t gid = 0; gid < limit; gid++) {
+        if (I(c, FLX_COL_PHASE, gid) != MK_SPLAT_SAMPLE) continue;
+        f3 Ei = R3(c, FLX_COL_EI, gid);
+        float *px = &c.pixels[(size_t)gid * 4];
+        float col[4] = {Ei.x, Ei.y, Ei.z, 1.0f};
+        if (px[3] > 0.0f) for (int k = 0; k < 4; k++) col[k] += px[k];
+        for (int k = 0; k < 4; k++) px[k] = col[k];
+        c.mkStats[3]++;
+        W3(c, FLX_COL_EI, gid, mk3(0.0f)); W3(c, FLX_COL_T, gid, mk3(1.0f));
+        U(c, FLX_COL_PATH_LEN, gid) = 0; U(c, FLX_COL_FIRST_DIFFUSE, gid) = 0;
+        I(c, FLX_COL_PHASE, gid) = MK_GENERATE_CAMERA_RAY;
+    }
+}
+
+/* reference: mk_splat_preview.cl:3-25 */
+void k_mk_splat_preview(Ctx &c)
+{
+    uint32_t limit = mkLimit(c);
+    for (uint32_t gid = 0; gid < limit; gid++) {
+        f3 Ei = R3(c, FLX_COL_EI, gid);
+        float *px = &c.pixels[(size_t)gid * 4];
+        px[0] = Ei.x; px[1] = Ei.y; px[2] = Ei.z; px[3] = 0.0f;
+        W3(c, FLX_COL_EI, gid, mk3(0.0f)); W3(c, FLX_COL_T, gid, mk3(1.0f));
+        U(c, FLX_COL_PATH_LEN, gid) = 0;
+        I(c, FLX_COL_PHASE, gid) = MK_GENERATE_CAMERA_RAY;
+    }
+}
+
 /* reference: tonemap.cl:3-26 */
 f3 uc2TonemapFunc(f3 x)
 {
@@ -1301,6 +1525,13 @@ int orc_wf_shadow(orc_ctx *p) { k_shadow(CTX(p)); return 0; }
 int orc_wf_logic(orc_ctx *p, int first) { k_logic(CTX(p), first); return 0; }
 int orc_wf_materials(orc_ctx *p) { k_materials(CTX(p)); return 0; }
 int orc_postprocess(orc_ctx *p) { k_postprocess(CTX(p)); return 0; }
+int orc_mk_reset(orc_ctx *p) { k_mk_reset(CTX(p)); return 0; }
+int orc_mk_raygen(orc_ctx *p) { k_mk_raygen(CTX(p)); return 0; }
+int orc_mk_next_vertex(orc_ctx *p) { k_mk_next_vertex(CTX(p)); return 0; }
+int orc_mk_sample_bsdf(orc_ctx *p) { k_mk_sample_bsdf(CTX(p)); return 0; }
+int orc_mk_splat(orc_ctx *p) { k_mk_splat(CTX(p)); return 0; }
+int orc_mk_splat_preview(orc_ctx *p) { k_mk_splat_preview(CTX(p)); return 0; }
+int orc_mk_stats(orc_ctx *p, uint32_t *out4, int reset) { Ctx &c = CTX(p); memcpy(out4, c.mkStats, 16); if (reset) memset(c.mkStats, 0, 16); return 0; }
 int orc_clear_queues(orc_ctx *p) { memset(&CTX(p).counters, 0, sizeof(flx_queue_counters)); return 0; }
 int orc_get_counters(orc_ctx *p, void *out32) { memcpy(out32, &CTX(p).counters, 32); return 0; }
 int orc_set_counters(orc_ctx *p, const void *in32) { memcpy(&CTX(p).counters, in32, 32); return 0; }

@@ -148,3 +148,55 @@ def test_egyptcat_real_asset_textured_glossy():
     p["maxBounces"] = 4
     a, b = _pair(d, p, n)
     _iterate(a, b, w * h, 8, rtol=1e-4, atol=1e-5, mat_rtol=2e-3)
+
+
+# ---------------------------------------------------------------- microkernel integrator
+MK_PHASES = (("raygen", lambda c: c.mk_raygen()), ("next_vertex", lambda c: c.mk_next_vertex()), ("sample_bsdf", lambda c: c.mk_sample_bsdf()))
+
+
+def _mk_step(a, b, name, fn, rtol, atol):
+    b.state_import(a.state_export())
+    fn(a); fn(b)
+    sa, sb = a.state_export(), b.state_export()
+    # a path whose sampler rejected (bsdf == 0) divides by the reference's uninitialised pdfW: its T / lastPdfW are dead
+    # (phase -> splat resets them) and undefined in the reference
+    dead = np.zeros(sa.shape[1], bool)
+    if name == "sample_bsdf":
+        t = sa[COL.T:COL.T + 3]
+        dead = ~np.isfinite(t).all(0) | ((t == 0).all(0))
+    fails = common.state_diff(sa, sb, rtol, atol, mask=~dead)
+    assert not fails, f"{name}: " + "; ".join(fails[:5])
+    assert np.array_equal(sa.view(np.uint32)[COL.PHASE], sb.view(np.uint32)[COL.PHASE]), name
+
+
+@pytest.mark.parametrize("area,env,expl,impl,roulette", [(1, 0, 1, 1, 0), (0, 1, 1, 1, 0), (1, 1, 1, 1, 1), (1, 1, 0, 1, 0), (1, 1, 1, 0, 0)])
+def test_microkernel_integrator_lockstep(area, env, expl, impl, roulette):
+    d = common.mixed_material_scene()
+    w, h = 48, 32
+    n = w * h
+    p = common.scene_params(d, w, h, maxBounces=4, useAreaLight=area, useEnvMap=env, sampleExpl=expl, sampleImpl=impl, useRoulette=roulette,
+                            envMapStrength=1.5)
+    from oracle.binding import RefContext
+    a, b = OracleContext(n), RefContext(n)
+    e = host.synthetic_sky(64, 32)
+    for c in (a, b):
+        c.upload_scene(d); c.upload_envmap(e); c.set_params(p)
+        c.mk_reset()
+    fails = common.state_diff(a.state_export(), b.state_export(), 0, 0, skip_cols=[COL.P, COL.P + 1, COL.P + 2])
+    for spp in range(3):
+        _mk_step(a, b, "raygen", MK_PHASES[0][1], RTOL, ATOL)
+        for bounce in range(int(p["maxBounces"]) + 1):
+            _mk_step(a, b, "next_vertex", MK_PHASES[1][1], 1e-4, 1e-5)
+            _mk_step(a, b, "sample_bsdf", MK_PHASES[2][1], 1e-3, 1e-5)
+        b.state_import(a.state_export())
+        a.mk_splat(); b.mk_splat()
+        assert np.allclose(a.read_pixels(0), b.read_pixels(0), rtol=1e-3, atol=1e-4)
+        assert np.array_equal(a.read_pixels(0)[:, 3], b.read_pixels(0)[:, 3])
+        assert not common.state_diff(a.state_export(), b.state_export(), 1e-4, 1e-5)
+    sa, sb = a.mk_stats(), b.mk_stats()
+    assert np.array_equal(sa, sb)
+    if not roulette:                                                  # renderSingle switches roulette off (src/tracer.cpp:104-108):
+        assert (a.read_pixels(0)[:, 3] == 3).all()                  # then every pass adds exactly one sample to every pixel
+        assert sa[3] == 3 * n and sa[0] == 3 * n
+    a.mk_splat_preview(); b.mk_splat_preview()
+    assert np.allclose(a.read_pixels(0), b.read_pixels(0), rtol=1e-3, atol=1e-4)
