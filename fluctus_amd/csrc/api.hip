@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <utility>
 
 namespace flxd {
 void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
@@ -19,6 +20,11 @@ void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, co
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
 void launch_state_export(hipStream_t, const State &, float *);
 void launch_state_import(hipStream_t, const State &, const float *);
+void launch_mk_reset(hipStream_t, const State &, const Frame &, const flx_render_params &);
+void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
+void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *);
+void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *);
+void launch_mk_splat(hipStream_t, const State &, const Frame &, const flx_render_params &, uint32_t *, int);
 void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t);
 }
 
@@ -52,6 +58,8 @@ struct flx_ctx {
     uint32_t *spill = nullptr;
     unsigned long long *stats = nullptr;   // device, 7 counters
     unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
+    uint32_t *mkStats = nullptr;           // device RenderStats of the microkernel integrator (4 x u32)
+    uint32_t *pinnedMk = nullptr; std::vector<std::pair<void *, int>> pendingMk; int nextMkSlot = 0;
     bool statsOn = false;
     int xcdRemap = 0;           // 1: each XCD gets a contiguous eighth of the queue (measured slower: round-robin keeps all XCDs on the same part of the tree)
     int compact = 1;            // use the 32-byte compact node records when the tree allows it
@@ -143,6 +151,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
         (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
     }
+    if (dalloc(c, c->fixedAllocs, &c->st.phase, N) || dalloc(c, c->fixedAllocs, &c->mkStats, 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->st.phase, 0, N * 4, c->stream); (void)hipMemsetAsync(c->mkStats, 0, 16, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->st.blocked, N) || dalloc(c, c->fixedAllocs, &c->st.pickProb, N) || dalloc(c, c->fixedAllocs, &c->st.firstDiffuse, N))
         return fail("hipMalloc(state)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->st.blocked, 0, N * 4, c->stream); (void)hipMemsetAsync(c->st.pickProb, 0, N * 4, c->stream); (void)hipMemsetAsync(c->st.firstDiffuse, 0, N * 4, c->stream);
@@ -168,6 +178,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     c->fr.rank = 0; c->fr.nranks = 1; c->fr.localPixels = 0;
     if ((e = hipHostMalloc((void **)&c->pinned, sizeof(flx_queue_counters) * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
     if ((e = hipHostMalloc((void **)&c->pinnedIdx, sizeof(uint32_t) * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void **)&c->pinnedMk, 16 * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
     // dummy 1x1 black environment map (reference: CLContext::setupScene, src/clcontext.cpp:513-518)
     {
         float4 *rgba; float *prob, *pdf; int *alias;
@@ -191,6 +202,7 @@ int flx_destroy(flx_ctx *c)
     freeAll(c->sceneAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->fixedAllocs);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
+    if (c->pinnedMk) (void)hipHostFree(c->pinnedMk);
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -410,6 +422,25 @@ int flx_wf_logic(flx_ctx *c, int first)
 int flx_wf_materials(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); } LAUNCHED(c); return 0; }
 int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
+// ---- microkernel integrator
+int flx_mk_reset(flx_ctx *c) { READY(c); launch_mk_reset(c->stream, c->st, c->fr, c->params); LAUNCHED(c); return 0; }
+int flx_mk_raygen(flx_ctx *c) { READY(c); launch_mk_raygen(c->stream, c->st, c->params); LAUNCHED(c); return 0; }
+int flx_mk_next_vertex(flx_ctx *c) { READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_sample_bsdf(flx_ctx *c) { READY(c); launch_mk_sample_bsdf(c->stream, c->st, c->sc, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_splat(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 0); LAUNCHED(c); return 0; }
+int flx_mk_splat_preview(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
+int flx_mk_stats_async(flx_ctx *c, void *out16)
+{
+    NEED(c, out16, "flx_mk_stats_async: null");
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((int)c->pendingMk.size() >= c->pinnedSlots) { c->err = "too many outstanding stats reads; call flx_finish"; return 1; }
+    int slot = c->nextMkSlot; c->nextMkSlot = (c->nextMkSlot + 1) % c->pinnedSlots;
+    HIPCHK(c, hipMemcpyAsync(c->pinnedMk + 4 * slot, c->mkStats, 16, hipMemcpyDeviceToHost, c->stream));
+    c->pendingMk.push_back({out16, slot});
+    return 0;
+}
+int flx_mk_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
+
 int flx_clear_queues(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
@@ -429,6 +460,8 @@ int flx_finish(flx_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
     c->pending.clear();
+    for (auto &p : c->pendingMk) memcpy(p.first, c->pinnedMk + 4 * p.second, 16);
+    c->pendingMk.clear();
     for (auto &ev : c->events) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { c->kMs[ev.kernel] += ms; c->kLaunches[ev.kernel]++; }

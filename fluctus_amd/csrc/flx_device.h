@@ -37,6 +37,7 @@ struct State {
     uint32_t *blocked;            // shadowRayBlocked
     float *pickProb;              // lastLightPickProb
     uint32_t *firstDiffuse;       // carried for export parity only
+    uint32_t *phase;              // PathPhase of the microkernel integrator (src/geom.h:183-192); untouched by the wavefront path
     uint32_t numTasks;
 };
 

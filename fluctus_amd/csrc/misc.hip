@@ -141,7 +141,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *ou
     const uint32_t fl = __float_as_uint(r.w);
     W(FLX_COL_AREA_LIGHT_HIT, __uint_as_float(fl & 1u)); W(FLX_COL_BACKFACE, __uint_as_float((fl >> 1) & 1u));
     r = rd4(st.rec[S_HITUV] + gid); W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
-    W(FLX_COL_PHASE, 0.0f);
+    W(FLX_COL_PHASE, __uint_as_float(st.phase[gid]));
     W(FLX_COL_SHADOW_BLOCKED, __uint_as_float(st.blocked[gid]));
     W(FLX_COL_LAST_PICK_PROB, st.pickProb[gid]);
     W(FLX_COL_FIRST_DIFFUSE, __uint_as_float(st.firstDiffuse[gid]));
@@ -170,6 +170,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const flo
     st.blocked[gid] = __float_as_uint(R(FLX_COL_SHADOW_BLOCKED));
     st.pickProb[gid] = R(FLX_COL_LAST_PICK_PROB);
     st.firstDiffuse[gid] = __float_as_uint(R(FLX_COL_FIRST_DIFFUSE));
+    st.phase[gid] = __float_as_uint(R(FLX_COL_PHASE));
 }
 
 __global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels)

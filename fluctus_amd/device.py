@@ -20,7 +20,8 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
-           "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option"]
+           "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
+           "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
 KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7}
 
@@ -117,6 +118,21 @@ class HipContext:
     def wf_materials(self): self._chk(self.L.flx_wf_materials(self.h))
     def postprocess(self): self._chk(self.L.flx_postprocess(self.h))
     def clear_queues(self): self._chk(self.L.flx_clear_queues(self.h))
+    # microkernel integrator
+    def mk_reset(self): self._chk(self.L.flx_mk_reset(self.h))
+    def mk_raygen(self): self._chk(self.L.flx_mk_raygen(self.h))
+    def mk_next_vertex(self): self._chk(self.L.flx_mk_next_vertex(self.h))
+    def mk_sample_bsdf(self): self._chk(self.L.flx_mk_sample_bsdf(self.h))
+    def mk_splat(self): self._chk(self.L.flx_mk_splat(self.h))
+    def mk_splat_preview(self): self._chk(self.L.flx_mk_splat_preview(self.h))
+
+    def mk_stats(self, reset=False):
+        out = np.zeros(4, np.uint32)
+        self._chk(self.L.flx_mk_stats_async(self.h, _p(out)))
+        if reset:
+            self._chk(self.L.flx_mk_stats_reset(self.h))
+        self.finish()
+        return out
 
     def get_counters(self):
         """Asynchronous: the returned array is filled by the next finish()."""

@@ -51,3 +51,26 @@ def first_frame(ctx, params, npix):
     cnt = np.array(cnt, copy=True)
     ctx.pixel_index_update(npix, int(cnt[0]))
     return cnt
+
+
+def render_single_pass(ctx, max_bounces):
+    """One sample per pixel with the microkernel integrator: the loop body of Tracer::renderSingle
+    (reference: src/tracer.cpp:131-141)."""
+    ctx.mk_raygen()
+    for _ in range(int(max_bounces) + 1):
+        ctx.mk_next_vertex()
+        ctx.mk_sample_bsdf()
+    ctx.mk_splat()
+
+
+def render_single(ctx, params, spp):
+    """Tracer::renderSingle (src/tracer.cpp:95-169): roulette off, reset, spp passes, post-process."""
+    p = params.copy()
+    p["useRoulette"] = 0
+    ctx.set_params(p)
+    ctx.mk_reset()
+    for _ in range(spp):
+        render_single_pass(ctx, p["maxBounces"])
+    ctx.postprocess()
+    ctx.finish()
+    return p

@@ -90,6 +90,22 @@ int flx_postprocess(flx_ctx *ctx);
  * sample count), 1 = post-processed preview.  Blocking; out = float4 per (local) pixel. */
 int flx_read_pixels(flx_ctx *ctx, int which, float *out_rgba);
 
+/* ---- microkernel integrator (the reference's second integrator).  One path per pixel (needs
+ * num_tasks >= width*height to cover the image), `phase` state machine, exactly one sample per pixel per pass.
+ * enqueueResetKernel / RayGenKernel / NextVertexKernel / BsdfSampleKernel / SplatKernel / SplatPreviewKernel
+ * (src/clcontext.cpp:709-750; kernels src/mk_reset.cl, mk_raygen.cl, mk_next_vertex.cl, mk_sample_bsdf.cl, mk_splat.cl,
+ * mk_splat_preview.cl).  Single-GPU (the pixel partition applies to the wavefront path only). */
+int flx_mk_reset(flx_ctx *ctx);
+int flx_mk_raygen(flx_ctx *ctx);
+int flx_mk_next_vertex(flx_ctx *ctx);
+int flx_mk_sample_bsdf(flx_ctx *ctx);
+int flx_mk_splat(flx_ctx *ctx);
+int flx_mk_splat_preview(flx_ctx *ctx);
+/* fetchStatsAsync / resetStats (src/clcontext.cpp:634-646): RenderStats {primaryRays, extensionRays, shadowRays, samples}
+ * (4 x u32, src/geom.h:254-260) accumulated on the device by the microkernels; *out16 valid after flx_finish() */
+int flx_mk_stats_async(flx_ctx *ctx, void *out16);
+int flx_mk_stats_reset(flx_ctx *ctx);
+
 /* ---- multi-GPU (no counterpart in the reference: one cl::CommandQueue, one device).
  * Rank r of R owns global pixels p*R + r; its framebuffer holds ceil((w*h - r)/R) local pixels. */
 int flx_set_partition(flx_ctx *ctx, uint32_t rank, uint32_t nranks);

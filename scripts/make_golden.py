@@ -90,7 +90,23 @@ def raygen():
     print("raygen.npz")
 
 
+def mk_teapot():
+    """BASELINE.json configs[0] on the microkernel path: teapot.ply, 128x128, 4 bounces, Lambertian, 16 spp."""
+    d = host.load_scene("/root/reference/assets/teapot.ply")
+    host.build_bvh(d, "sbvh")
+    w = h = 128
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    p["maxBounces"] = 4
+    c = RefContext(w * h)
+    c.upload_scene(d)
+    driver.render_single(c, p, 16)
+    np.savez_compressed(os.path.join(OUT, "mk_teapot.npz"), num_tasks=w * h, spp=16, params=np.asarray(p).reshape(1).view(np.uint8),
+                        pixels=c.read_pixels(0), stats=c.mk_stats(), **scene_arrays(d))
+    print("mk_teapot.npz", c.mk_stats())
+
+
 if __name__ == "__main__":
+    mk_teapot()
     teapot()
     steps("area_sep", useAreaLight=1, useEnvMap=0, wfSeparateQueues=1)
     steps("env_area_single_rr", useAreaLight=1, useEnvMap=1, wfSeparateQueues=0, useRoulette=1)

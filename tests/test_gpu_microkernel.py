@@ -1,0 +1,101 @@
+"""GPU parity of the microkernel integrator: libfluctus_hip.so vs the CPU oracle, bit-exact, and
+vs the reference kernels' own output (golden fixture)."""
+import os
+import numpy as np
+import pytest
+import common
+from common import COL
+from fluctus_amd import host, wire, driver
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctxs(d, p, n, env=None):
+    from fluctus_amd.device import HipContext
+    from oracle.binding import OracleContext
+    g, o = HipContext(n), OracleContext(n, threads=8)
+    for c in (g, o):
+        c.upload_scene(d)
+        if env is not None:
+            c.upload_envmap(env)
+        c.set_params(p)
+    return g, o
+
+
+@pytest.mark.parametrize("area,env,expl,impl,roulette", [(1, 0, 1, 1, 0), (0, 1, 1, 1, 0), (1, 1, 1, 1, 1), (1, 1, 0, 1, 0), (1, 1, 1, 0, 0)])
+def test_microkernel_lockstep_bit_exact(area, env, expl, impl, roulette):
+    d = common.mixed_material_scene()
+    w, h = 64, 48
+    n = w * h + 100                           # numTasks > pixels: the limit is min(w*h, numTasks)
+    p = common.scene_params(d, w, h, maxBounces=4, useAreaLight=area, useEnvMap=env, sampleExpl=expl, sampleImpl=impl, useRoulette=roulette,
+                            envMapStrength=1.5)
+    g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
+    for c in (g, o):
+        c.mk_reset()
+    steps = [("raygen", lambda c: c.mk_raygen())] + [(k, f) for _ in range(5) for k, f in (("next_vertex", lambda c: c.mk_next_vertex()),
+                                                                                        ("sample_bsdf", lambda c: c.mk_sample_bsdf()))]
+    for spp in range(3):
+        for name, fn in steps + [("splat", lambda c: c.mk_splat())]:
+            g.state_import(o.state_export())
+            fn(g); fn(o)
+            sa, sb = g.state_export(), o.state_export()
+            # NaN throughput of a rejected sample (0/0, dead value) compares equal bit for bit as well
+            fails = common.state_diff(sa, sb, 0.0, 0.0)
+            assert not fails, f"spp{spp} {name}: " + "; ".join(fails[:4])
+            assert np.array_equal(sa.view(np.uint32)[COL.PHASE], sb.view(np.uint32)[COL.PHASE])
+        assert np.array_equal(g.read_pixels(0).view(np.uint32), o.read_pixels(0).view(np.uint32))   # no atomics: exact
+    assert np.array_equal(g.mk_stats(), o.mk_stats())
+
+
+def test_render_single_exact_spp_and_image():
+    """Tracer::renderSingle semantics: every pixel gets exactly `spp` samples; image bit-identical to the oracle."""
+    d = common.mixed_material_scene()
+    w, h, spp = 96, 64, 6
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, useRoulette=1)   # roulette is switched off by render_single
+    g, o = _ctxs(d, p, w * h, env=host.synthetic_sky(64, 32))
+    driver.render_single(g, p, spp)
+    driver.render_single(o, p, spp)
+    pg, po = g.read_pixels(0), o.read_pixels(0)
+    assert (pg[:, 3] == spp).all()
+    assert np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+    assert np.array_equal(g.read_pixels(1).view(np.uint32), o.read_pixels(1).view(np.uint32))      # post-processed preview
+    st = g.mk_stats()
+    assert st[3] == spp * w * h and st[0] == spp * w * h
+
+
+def test_microkernel_preview_and_too_few_tasks():
+    """splatPreview (iteration-0 preview of Tracer::update's MK branch) and numTasks < pixels (only the first numTasks pixels render)."""
+    d = common.simple_scene()
+    w, h = 40, 30
+    p = common.scene_params(d, w, h, maxBounces=3)
+    g, o = _ctxs(d, p, 700)
+    for c in (g, o):
+        c.mk_reset(); c.mk_raygen(); c.mk_next_vertex(); c.mk_sample_bsdf(); c.mk_next_vertex(); c.mk_sample_bsdf(); c.mk_splat_preview()
+    pg, po = g.read_pixels(0), o.read_pixels(0)
+    assert np.array_equal(pg.view(np.uint32), po.view(np.uint32))
+    assert (pg[:, 3] == 0).all() and (pg[700:] == 0).all() and pg[:700, :3].sum() > 0
+    assert not common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+
+
+def test_microkernel_vs_reference_fixture():
+    """The reference's own microkernels (oracle/_ref) rendered tests/golden/mk_teapot.npz: teapot.ply, 16 spp, 4 bounces
+    (BASELINE.json configs[0]).  One path per pixel and no queues, so the comparison is per pixel."""
+    from fluctus_amd.device import HipContext
+    path = os.path.join(common.GOLDEN, "mk_teapot.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden fixture missing")
+    z = np.load(path)
+    d = host.SceneData()
+    d.tris = z["tris"].view(wire.TRIANGLE).reshape(-1); d.nodes = z["nodes"].view(wire.NODE).reshape(-1); d.indices = z["indices"]
+    d.materials = z["materials"].view(wire.MATERIAL).reshape(-1)
+    d.texdesc = np.zeros(0, wire.TEXDESC); d.texdata = np.zeros(0, np.uint8)
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    g = HipContext(int(z["num_tasks"]))
+    g.upload_scene(d)
+    driver.render_single(g, p, int(z["spp"]))
+    pg, ref = g.read_pixels(0), z["pixels"]
+    assert np.array_equal(pg[:, 3], ref[:, 3])
+    close = np.isclose(pg[:, :3], ref[:, :3], rtol=2e-3, atol=2e-3).all(1)
+    assert close.mean() > 0.99, close.mean()            # a path flips only when an ulp-level difference moves a grazing ray
+    assert abs(pg[:, :3].mean() - ref[:, :3].mean()) <= 2e-3 * ref[:, :3].mean()
+    assert np.array_equal(g.mk_stats()[[0, 3]], z["stats"][[0, 3]])

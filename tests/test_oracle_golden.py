@@ -125,3 +125,20 @@ def test_thread_count_does_not_change_results():
         outs.append((np.stack(cn), c.state_export(), np.stack([c.queue_read(q) for q in range(8)])))
     assert np.array_equal(outs[0][0], outs[1][0])
     assert not common.state_diff(outs[0][1], outs[1][1], 0.0, 0.0)
+
+
+def test_microkernel_teapot_16spp_golden():
+    """BASELINE.json configs[0] ("teapot.ply, 4 bounces, Lambertian only, 16 spp") on the microkernel path, oracle vs the
+    reference's own microkernels (tests/golden/mk_teapot.npz)."""
+    z = _fixture("mk_teapot.npz")
+    d = _load_scene(z)
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    c = OracleContext(int(z["num_tasks"]), threads=4)
+    c.upload_scene(d)
+    driver.render_single(c, p, int(z["spp"]))
+    px, ref = c.read_pixels(0), z["pixels"]
+    assert np.array_equal(px[:, 3], ref[:, 3]) and (px[:, 3] == 16).all()
+    close = np.isclose(px[:, :3], ref[:, :3], rtol=2e-3, atol=2e-3).all(1)
+    assert close.mean() > 0.99
+    assert abs(px[:, :3].mean() - ref[:, :3].mean()) <= 2e-3 * ref[:, :3].mean()
+    assert np.array_equal(c.mk_stats()[[0, 3]], z["stats"][[0, 3]])
