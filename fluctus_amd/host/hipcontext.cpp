@@ -14,6 +14,8 @@ struct HipContext::Api {
     FN(flx_wf_reset) FN(flx_wf_raygen) FN(flx_wf_extend) FN(flx_wf_shadow) FN(flx_wf_logic) FN(flx_wf_materials)
     FN(flx_clear_queues) FN(flx_get_counters_async) FN(flx_finish) FN(flx_pixel_index_update) FN(flx_pixel_index_reset)
     FN(flx_num_tasks) FN(flx_postprocess) FN(flx_read_pixels) FN(flx_set_partition) FN(flx_local_pixels)
+    FN(flx_mk_reset) FN(flx_mk_raygen) FN(flx_mk_next_vertex) FN(flx_mk_sample_bsdf) FN(flx_mk_splat) FN(flx_mk_splat_preview)
+    FN(flx_mk_stats_async) FN(flx_mk_stats_reset)
 #undef FN
 };
 
@@ -39,6 +41,8 @@ HipContext::HipContext(int device, uint32_t numTasks, const std::string &libPath
     BIND(flx_wf_reset) BIND(flx_wf_raygen) BIND(flx_wf_extend) BIND(flx_wf_shadow) BIND(flx_wf_logic) BIND(flx_wf_materials)
     BIND(flx_clear_queues) BIND(flx_get_counters_async) BIND(flx_finish) BIND(flx_pixel_index_update) BIND(flx_pixel_index_reset)
     BIND(flx_num_tasks) BIND(flx_postprocess) BIND(flx_read_pixels) BIND(flx_set_partition) BIND(flx_local_pixels)
+    BIND(flx_mk_reset) BIND(flx_mk_raygen) BIND(flx_mk_next_vertex) BIND(flx_mk_sample_bsdf) BIND(flx_mk_splat) BIND(flx_mk_splat_preview)
+    BIND(flx_mk_stats_async) BIND(flx_mk_stats_reset)
 #undef BIND
     if (api->flx_create(device, numTasks, &ctx) != 0)
         throw std::runtime_error(std::string("HipContext: ") + api->flx_last_error(nullptr));
@@ -76,10 +80,27 @@ void HipContext::enqueueWfExtRayKernel(const RenderParams &) { check(api->flx_wf
 void HipContext::enqueueWfShadowRayKernel(const RenderParams &) { check(api->flx_wf_shadow(ctx), "wf_shadow"); }
 void HipContext::enqueueWfLogicKernel(const RenderParams &, bool first) { check(api->flx_wf_logic(ctx, first ? 1 : 0), "wf_logic"); }
 void HipContext::enqueueWfMaterialKernels(const RenderParams &) { check(api->flx_wf_materials(ctx), "wf_materials"); }
+// microkernel integrator (src/clcontext.cpp:709-748)
+void HipContext::enqueueResetKernel(const RenderParams &) { check(api->flx_mk_reset(ctx), "mk_reset"); }
+void HipContext::enqueueRayGenKernel(const RenderParams &) { check(api->flx_mk_raygen(ctx), "mk_raygen"); }
+void HipContext::enqueueNextVertexKernel(const RenderParams &) { check(api->flx_mk_next_vertex(ctx), "mk_next_vertex"); }
+void HipContext::enqueueBsdfSampleKernel(const RenderParams &) { check(api->flx_mk_sample_bsdf(ctx), "mk_sample_bsdf"); }
+void HipContext::enqueueSplatKernel(const RenderParams &) { check(api->flx_mk_splat(ctx), "mk_splat"); }
+void HipContext::enqueueSplatPreviewKernel(const RenderParams &) { check(api->flx_mk_splat_preview(ctx), "mk_splat_preview"); }
+// reference: CLContext::fetchStatsAsync (src/clcontext.cpp:642-646): the device counters since the last reset land in
+// mkStats at the next finishQueue(); foldMkStats() then moves them into statsAsync (64-bit) and zeroes the device side,
+// so the 32-bit device counters (src/geom.h:254-260) cannot wrap in a long render.
+void HipContext::fetchStatsAsync() { check(api->flx_mk_stats_async(ctx, mkStats), "fetch stats"); check(api->flx_mk_stats_reset(ctx), "reset stats"); mkPending = true; }
+void HipContext::foldMkStats()
+{
+    if (!mkPending) return;
+    statsAsync.primaryRays += mkStats[0]; statsAsync.extensionRays += mkStats[1]; statsAsync.shadowRays += mkStats[2]; statsAsync.samples += mkStats[3];
+    mkStats[0] = mkStats[1] = mkStats[2] = mkStats[3] = 0; mkPending = false;
+}
 void HipContext::enqueueClearWfQueues() { check(api->flx_clear_queues(ctx), "clear queues"); }
 void HipContext::enqueueGetCounters(QueueCounters *cnt) { check(api->flx_get_counters_async(ctx, cnt), "get counters"); }
 void HipContext::enqueuePostprocessKernel(const RenderParams &) { check(api->flx_postprocess(ctx), "postprocess"); }
-void HipContext::finishQueue() { check(api->flx_finish(ctx), "finish"); }
+void HipContext::finishQueue() { check(api->flx_finish(ctx), "finish"); foldMkStats(); }
 void HipContext::updatePixelIndex(uint32_t n, uint32_t nnew) { check(api->flx_pixel_index_update(ctx, n, nnew), "updatePixelIndex"); }
 void HipContext::resetPixelIndex() { check(api->flx_pixel_index_reset(ctx), "resetPixelIndex"); }
 uint32_t HipContext::getNumTasks() const { return api->flx_num_tasks(ctx); }

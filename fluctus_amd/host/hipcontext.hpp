@@ -1,7 +1,7 @@
 // hipcontext.hpp -- C++ device context over the C ABI of libfluctus_hip.so.
 //
 // Same method surface as the reference's `class CLContext` (reference: src/clcontext.hpp:31-79) for the
-// wavefront path, so the Tracer loop reads like the reference's; every method forwards to one flx_* entry
+// wavefront path and the microkernel integrator, so the Tracer loop reads like the reference's; every method forwards to one flx_* entry
 // point (include/fluctus_hip.h).  The HIP library is bound with dlopen at construction: libfluctus_host.so
 // itself has no GPU dependency and there is NO CPU fallback -- a missing library or device throws.
 #pragma once
@@ -35,6 +35,14 @@ public:
     void enqueueWfShadowRayKernel(const RenderParams &params);
     void enqueueWfLogicKernel(const RenderParams &params, bool firstIteration);
     void enqueueWfMaterialKernels(const RenderParams &params);
+    // microkernel integrator (src/clcontext.hpp:45-51)
+    void enqueueResetKernel(const RenderParams &params);
+    void enqueueRayGenKernel(const RenderParams &params);
+    void enqueueNextVertexKernel(const RenderParams &params);
+    void enqueueBsdfSampleKernel(const RenderParams &params);
+    void enqueueSplatKernel(const RenderParams &params);
+    void enqueueSplatPreviewKernel(const RenderParams &params);
+    void fetchStatsAsync();                                       // src/clcontext.cpp:642-646; folded into statsAsync by finishQueue()
     void enqueueClearWfQueues();                                  // src/clcontext.cpp:877-883
     void enqueueGetCounters(QueueCounters *cnt);                  // async; valid after finishQueue()
     void enqueuePostprocessKernel(const RenderParams &params);
@@ -60,6 +68,9 @@ public:
 
 private:
     void check(int rc, const char *what);
+    void foldMkStats();
+    uint32_t mkStats[4] = {0, 0, 0, 0};
+    bool mkPending = false;
     void *dl = nullptr;
     flx_ctx *ctx = nullptr;
     PerfNumbers renderPerf;

@@ -138,6 +138,13 @@ int fh_tracer_params(void *t, void *out240, const void *in240)
     FH_CATCH
 }
 int fh_tracer_update(void *t, void *counters32) { FH_TRY ((Tracer *)t)->update(); if (counters32) memcpy(counters32, &((Tracer *)t)->lastCounters(), 32); FH_CATCH }
+int fh_tracer_render_single(void *t, int spp) { FH_TRY ((Tracer *)t)->renderSingle(spp); FH_CATCH }
+int fh_tracer_toggle_renderer(void *t) { FH_TRY ((Tracer *)t)->toggleRenderer(); FH_CATCH }
+int fh_tracer_uses_wavefront(void *t) { return ((Tracer *)t)->usesWavefront() ? 1 : 0; }
+int fh_tracer_stats(void *t, uint64_t *out4)
+{
+    FH_TRY RenderStats s = ((Tracer *)t)->getContext()->getStats(); out4[0] = s.primaryRays; out4[1] = s.extensionRays; out4[2] = s.shadowRays; out4[3] = s.samples; FH_CATCH
+}
 int fh_tracer_run_benchmark(void *t, double seconds, int iterations, char *csv, uint64_t cap)
 {
     FH_TRY

@@ -104,10 +104,57 @@ void Tracer::setEnvMap(const std::string &hdrFile)
     paramsUpdatePending = true;
 }
 
-// reference: src/tracer.cpp:189-358, wavefront branch
+// reference: src/tracer.cpp:95-187
+void Tracer::renderSingle(int spp)
+{
+    if (useWavefront) toggleRenderer();                                  // only MK guarantees the spp of every pixel (:99-101)
+    if ((uint64_t)params.width * params.height > clctx->getNumTasks())
+        throw std::runtime_error("renderSingle: width*height exceeds the context's numTasks (one path per pixel)");
+    params.useRoulette = 0;                                              // :104-108
+    clctx->updateParams(params); paramsUpdatePending = false;
+    clctx->enqueueResetKernel(params);
+    for (int sample = 0; sample < spp; sample++) {
+        clctx->enqueueRayGenKernel(params);
+        for (uint32_t bounce = 0; bounce < params.maxBounces + 1; bounce++) {
+            clctx->enqueueNextVertexKernel(params);
+            clctx->enqueueBsdfSampleKernel(params);
+        }
+        clctx->enqueueSplatKernel(params);
+        clctx->enqueuePostprocessKernel(params);
+        clctx->fetchStatsAsync();
+        clctx->finishQueue();
+        iteration++;
+    }
+}
+
+// reference: src/tracer.cpp:268-299, microkernel branch of update()
+void Tracer::updateMicrokernel()
+{
+    if (iteration == 0) {                                                // interactive preview: two segments, splat incomplete paths
+        clctx->enqueueResetKernel(params);
+        clctx->enqueueRayGenKernel(params);
+        clctx->enqueueNextVertexKernel(params);
+        clctx->enqueueBsdfSampleKernel(params);
+        clctx->enqueueNextVertexKernel(params);
+        clctx->enqueueBsdfSampleKernel(params);
+        clctx->enqueueSplatPreviewKernel(params);
+    } else {                                                             // one state-machine step of every path per frame
+        clctx->enqueueRayGenKernel(params);
+        clctx->enqueueNextVertexKernel(params);
+        clctx->enqueueBsdfSampleKernel(params);
+        clctx->enqueueSplatKernel(params);
+    }
+    clctx->enqueuePostprocessKernel(params);
+    clctx->fetchStatsAsync();                                            // :343-344
+    clctx->finishQueue();
+    iteration++;
+}
+
+// reference: src/tracer.cpp:189-358
 void Tracer::update()
 {
     if (paramsUpdatePending) { clctx->updateParams(params); paramsUpdatePending = false; iteration = 0; }
+    if (!useWavefront) { updateMicrokernel(); return; }
     QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
     uint32_t maxBounces = params.maxBounces;
     int N = 1;
@@ -155,6 +202,8 @@ std::string Tracer::runBenchmark(double seconds, int iterations)
     clctx->resetPixelIndex();
     clctx->enqueueWfResetKernel(params);
     clctx->enqueueClearWfQueues();
+    clctx->enqueueResetKernel(params);                                   // :377
+    clctx->fetchStatsAsync();                                            // drains + zeroes the device-side MK counters
     clctx->finishQueue();
     clctx->resetStats();
     double startT = now(), lastLog = startT, currT = startT;
@@ -167,19 +216,29 @@ std::string Tracer::runBenchmark(double seconds, int iterations)
     };
     while (iterations > 0 ? it < iterations : currT - startT < seconds) {
         QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
-        clctx->enqueueWfLogicKernel(params, false);
-        clctx->enqueueWfRaygenKernel(params);
-        clctx->enqueueWfMaterialKernels(params);
-        clctx->enqueueGetCounters(&cnt);
-        clctx->enqueueWfExtRayKernel(params);
-        clctx->enqueueWfShadowRayKernel(params);
-        clctx->enqueueClearWfQueues();
+        if (useWavefront) {
+            clctx->enqueueWfLogicKernel(params, false);
+            clctx->enqueueWfRaygenKernel(params);
+            clctx->enqueueWfMaterialKernels(params);
+            clctx->enqueueGetCounters(&cnt);
+            clctx->enqueueWfExtRayKernel(params);
+            clctx->enqueueWfShadowRayKernel(params);
+            clctx->enqueueClearWfQueues();
+        } else {                                                         // :441-447
+            clctx->enqueueRayGenKernel(params);
+            clctx->enqueueNextVertexKernel(params);
+            clctx->enqueueBsdfSampleKernel(params);
+            clctx->enqueueSplatKernel(params);
+            clctx->fetchStatsAsync();
+        }
         clctx->enqueuePostprocessKernel(params);
         clctx->finishQueue();
-        clctx->statsAsync.extensionRays += cnt.extensionQueue;
-        clctx->statsAsync.shadowRays += cnt.shadowQueue;
-        clctx->statsAsync.primaryRays += cnt.raygenQueue;
-        clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
+        if (useWavefront) {
+            clctx->statsAsync.extensionRays += cnt.extensionQueue;
+            clctx->statsAsync.shadowRays += cnt.shadowQueue;
+            clctx->statsAsync.primaryRays += cnt.raygenQueue;
+            clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
+        }
         clctx->updatePixelIndex(clctx->localPixels(), cnt.raygenQueue);
         lastCnt = cnt;
         iteration++; it++;

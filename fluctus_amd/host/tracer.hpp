@@ -3,8 +3,8 @@
 // Restates the wavefront branch of the reference's Tracer (reference: src/tracer.hpp:31-43,
 // src/tracer.cpp): resetParams (:38-52), init (:55-80), initHierarchy (:574-590, BVH cache keyed by a hash of
 // the mesh), update() WF branch (:222-266, :302-340) and runBenchmark() WF body (:362-528, CSV schema
-// `scene;time;primary;extension;shadow;total;samples` :393).  No window, no GL, no microkernel integrator
-// (out of scope).
+// `scene;time;primary;extension;shadow;total;samples` :393), plus the microkernel integrator's branches of the same
+// functions and renderSingle (:95-187).  No window, no GL, no denoiser.
 #pragma once
 #include <memory>
 #include <string>
@@ -23,6 +23,11 @@ public:
     // benchmark-style iterations for `seconds` (reference: 30 s per scene) or exactly `iterations` if > 0;
     // returns the CSV text (header + one row per 0.5 s of wall time)
     std::string runBenchmark(double seconds, int iterations = 0);
+    // final-frame render: exactly `spp` samples in every pixel (reference: src/tracer.cpp:95-187).  Switches to the
+    // microkernel integrator and turns Russian roulette off, as the reference does; needs numTasks >= width*height.
+    void renderSingle(int spp);
+    void toggleRenderer() { useWavefront = !useWavefront; iteration = 0; }        // src/tracer.cpp:881-886
+    bool usesWavefront() const { return useWavefront; }
     void saveImage(const std::string &filename) { clctx->saveImage(filename, params); }
 
     RenderParams &getParams() { return params; }
@@ -39,6 +44,7 @@ private:
     void initPostProcessing();
     void initAreaLight();
     void initHierarchy();
+    void updateMicrokernel();
 
     RenderParams params;
     std::unique_ptr<Scene> scene;
@@ -47,6 +53,7 @@ private:
     BVH *bvh = nullptr;
     uint32_t iteration = 0;
     bool paramsUpdatePending = true;
+    bool useWavefront = true;                                                     // this library's default; the reference starts on MK (src/tracer.cpp:11)
     QueueCounters lastCnt {};
     std::string sceneName;
 };

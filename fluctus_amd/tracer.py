@@ -44,6 +44,23 @@ class Tracer:
         host._chk(self.L.fh_tracer_update(self.h, cnt.ctypes.data_as(C.c_void_p)))
         return cnt
 
+    def render_single(self, spp):
+        """Tracer::renderSingle (src/tracer.cpp:95-187): exactly spp samples per pixel on the microkernel integrator."""
+        host._chk(self.L.fh_tracer_render_single(self.h, int(spp)))
+
+    def toggle_renderer(self):
+        host._chk(self.L.fh_tracer_toggle_renderer(self.h))
+
+    @property
+    def uses_wavefront(self):
+        return bool(self.L.fh_tracer_uses_wavefront(self.h))
+
+    def stats(self):
+        """RenderStats accumulated on the host: primary, extension, shadow rays, samples."""
+        out = np.zeros(4, np.uint64)
+        host._chk(self.L.fh_tracer_stats(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def run_benchmark(self, seconds=1.0, iterations=0):
         buf = C.create_string_buffer(1 << 20)
         host._chk(self.L.fh_tracer_run_benchmark(self.h, C.c_double(seconds), int(iterations), buf, C.c_uint64(len(buf))))
