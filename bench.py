@@ -142,8 +142,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FLX_FORCE_DIST=1: take the RCCL code path (init, barrier, all-reduce, tile gather) even with one rank, so it can be
+    # exercised on a 1-GPU box under `python -m torch.distributed.run --nproc-per-node 1`
+    use_dist = world > 1 or os.environ.get("FLX_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from fluctus_amd import device, driver
@@ -197,7 +201,7 @@ def main():
         ctx = _Group()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -222,7 +226,7 @@ def main():
     prof = ctx.profile_get()
     rays_local = float(tot[1]) + float(tot[2])
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -263,7 +267,7 @@ def main():
 
     # ---- multi-GPU: gather the radiance tiles over RCCL (outside the timed region)
     gather_ms = None
-    if world > 1:
+    if use_dist:
         lp = ctxs[0].local_pixels()
         maxlp = (args.width * args.height + world - 1) // world
         tile = torch.zeros((maxlp, 4), dtype=torch.float32, device="cuda")
@@ -312,7 +316,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
