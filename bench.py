@@ -47,6 +47,7 @@ def build_workload(width=None, height=None, name="kitchen"):
     from fluctus_amd import host, wire
     gen, tris, seed, bvh, w, h, bounces, use_env, use_area, cam, target = WORKLOADS[name]
     width, height = width or w, height or h
+    tris = int(os.environ.get("FLX_BENCH_TRIS", tris))          # experiments only (scripts/sweep.sh); the bench line uses the default
     d = host.generate_scene(gen, tris, seed)
     host.build_bvh(d, bvh)
     p = wire.default_params(width, height, d.world_radius, d.tris.size)
@@ -244,6 +245,15 @@ def main():
         step_async(ctx)
     ctx.finish()
     st = ctx.stats()
+    simd = None
+    if C == 1:
+        ws = ctx.wave_stats()
+        def eff(lane, wave): return lane / (64.0 * wave) if wave else None
+        simd = {"ext_inner": eff(st["ext_inner"], ws["ext"]["inner"]), "ext_tri": eff(st["ext_tri"], ws["ext"]["tri"]),
+                "shadow_inner": eff(st["shadow_inner"], ws["shadow"]["inner"]), "shadow_tri": eff(st["shadow_tri"], ws["shadow"]["tri"]),
+                "ext_outer_trips_per_wave": ws["ext"]["outer"] / max(1.0, st["ext_rays"] / 64.0),
+                "shadow_outer_trips_per_wave": ws["shadow"]["outer"] / max(1.0, st["shadow_rays"] / 64.0),
+                "ext_longest_ray_inner_per_wave": ws["ext_max_inner_sum"] / max(1.0, st["ext_rays"] / 64.0), "ext_wave_trips": ws["ext"], "shadow_wave_trips": ws["shadow"]}
     ctx.trace_stats_enable(False)
     ext_bytes, sh_bytes = algorithmic_bytes(st)
     bytes_per_ext_ray = ext_bytes / max(1, st["ext_rays"])
@@ -305,7 +315,7 @@ def main():
                          "avg_inner_visits": st["ext_inner"] / max(1, st["ext_rays"]),
                          "avg_tri_tests": st["ext_tri"] / max(1, st["ext_rays"]),
                          "hit_fraction": st["ext_hits"] / max(1, st["ext_rays"]),
-                         "launch_ms": ext_ms / max(1, ext_n),
+                         "launch_ms": ext_ms / max(1, ext_n), "simd_efficiency": simd,
                          "note": "k_extend runs concurrently with k_shadow (two streams); 'concurrent_traversal' = (extension + shadow "
                                  "algorithmic bytes) / span of the pair",
                          "concurrent_traversal": ({"achieved": combined, "frac": combined / HBM_PEAK_GBS, "span_ms": span_ms / span_n,

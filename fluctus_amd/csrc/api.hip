@@ -56,7 +56,7 @@ struct flx_ctx {
     uint8_t *member = nullptr; uint32_t *blockCounts = nullptr, *blockOffsets = nullptr;
     // trace aux
     uint32_t *spill = nullptr;
-    unsigned long long *stats = nullptr;   // device, 7 counters
+    unsigned long long *stats = nullptr;   // device, 16 counters
     unsigned long long *totals = nullptr;  // device, 8 running queue-length totals
     uint32_t *mkStats = nullptr;           // device RenderStats of the microkernel integrator (4 x u32)
     uint32_t *pinnedMk = nullptr; std::vector<std::pair<void *, int>> pendingMk; int nextMkSlot = 0;
@@ -169,8 +169,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->fetch, 16)) return fail("hipMalloc(fetch)", hipErrorOutOfMemory);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
-    if (dalloc(c, c->fixedAllocs, &c->stats, 8)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
-    (void)hipMemsetAsync(c->stats, 0, 64, c->stream);
+    if (dalloc(c, c->fixedAllocs, &c->stats, 16)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->stats, 0, 128, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
@@ -533,7 +533,14 @@ int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int flx_trace_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 64, c->stream)); return 0; }
+int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out16, c->stats, 128, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_trace_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 128, c->stream)); return 0; }
 
 // ---- test hooks
 int flx_state_export(flx_ctx *c, float *out)

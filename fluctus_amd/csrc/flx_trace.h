@@ -27,7 +27,7 @@ namespace flxd {
 struct TraceAux {
     uint32_t *spill;        // (MAX_LEVELS - LDS_LEVELS) x totalThreads
     uint32_t totalThreads;
-    unsigned long long *stats;   // 7 counters or nullptr
+    unsigned long long *stats;   // 16 counters (7 ray-level, [8..11] / [12..15] wave-level trips of k_extend / k_shadow) or nullptr
 };
 
 __device__ __forceinline__ bool slab(const float *bmin, const float *bmax, f3 orig, f3 dinv, float tMaxPrev, float *tnear)
@@ -108,19 +108,86 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks, int 
 }
 
 // One ray through the tree, reference visit order (near child first, leaf triangles in index order).
+//
+// Loop shape ("while-while", TRACE_LOOP 1): the inner `while` descends AND pops, so a lane leaves it only when it stands
+// on a leaf or has finished; the wave then intersects all pending leaves together.  The obvious single loop
+// (TRACE_LOOP 0: if inner / else leaf / pop at the bottom) is structurised by the compiler into descend-only inner
+// loops with the pop in the outer loop: every lane that dead-ends waits for the deepest descent of the wave --
+// measured 95 inner trips per wave against 46.5 for the wave's longest ray (bench.py roofline.simd_efficiency).
+#ifndef TRACE_LOOP
+#define TRACE_LOOP 1
+#endif
+#define FLX_RAY_DONE 0xFFFFFFFFu                  // leaf bit set: never taken for an inner node
+
 template <bool ANY_HIT, bool STATS>
 __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
-                                         int &tribest, uint32_t &nInner, uint32_t &nTri)
+                                         int &tribest, uint32_t &nInner, uint32_t &nTri, unsigned long long *wstats = nullptr)
 {
+    // STATS builds only: wave-level trip counts (SIMD efficiency = lane-level work / (64 x wave-level trips)):
+    // wstats[0] outer iterations, [1] executions of the inner-node branch, [2] of the leaf branch, [3] triangle-loop trips
+#define FLX_WAVE_TICK(k) do { if (STATS && wstats) { const uint64_t m_ = __ballot(true); \
+        if (lane_id() == (uint32_t)__ffsll((long long)m_) - 1u) atomicAdd(&wstats[k], 1ull); } } while (0)
     const f3 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     int sp = 0;
     uint32_t cur = sc.rootRef;
+#if TRACE_LOOP == 1
+    for (;;) {
+        FLX_WAVE_TICK(0);
+        while (!(cur & FLX_LEAF_BIT)) {
+            FLX_WAVE_TICK(1);
+            const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            const float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+            const float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+            const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            if (STATS) nInner++;
+            float lnear, rnear;
+            const bool lh = slab(lmin, lmax, orig, dinv, tbest, &lnear);
+            const bool rh = slab(rmin, rmax, orig, dinv, tbest, &rnear);
+            if (lh && rh) {
+                const bool goRight = rnear < lnear;
+                stk.push(sp++, goRight ? left : right);
+                cur = goRight ? right : left;
+            } else if (lh || rh) {
+                cur = lh ? left : right;
+            } else {
+                cur = (sp == 0) ? FLX_RAY_DONE : stk.pop(sp - 1);
+                sp = (sp == 0) ? 0 : sp - 1;
+            }
+        }
+        if (cur == FLX_RAY_DONE) break;
+        {
+            const uint32_t slot = cur & ~FLX_LEAF_BIT;
+            const float4 *tp = reinterpret_cast<const float4 *>(sc.trirecs + slot);
+            float4 a = tp[0], b = tp[1], c = tp[2];
+            const int count = __float_as_int(b.w);
+            FLX_WAVE_TICK(2);
+            for (int k = 0;;) {
+                FLX_WAVE_TICK(3);
+                if (STATS) nTri++;
+                float t, u, v;
+                if (moller_trumbore(orig, dir, ld3(a), ld3(b), ld3(c), &t, &u, &v) && t > 0.0f && t < tbest) {
+                    if (ANY_HIT) return true;
+                    tbest = t; ubest = u; vbest = v; tribest = __float_as_int(a.w);
+                }
+                if (++k >= count) break;
+                tp += 3;
+                a = tp[0]; b = tp[1]; c = tp[2];
+            }
+        }
+        if (sp == 0) break;
+        cur = stk.pop(--sp);
+    }
+    return false;
+#else
 #if TRACE_COMPACT
     bool boxKnown = false;
     float pmin[3] = {0.0f, 0.0f, 0.0f}, pmax[3] = {0.0f, 0.0f, 0.0f};
 #endif
     for (;;) {
+        FLX_WAVE_TICK(0);
         if (!(cur & FLX_LEAF_BIT)) {
+            FLX_WAVE_TICK(1);
             float lmin[3], lmax[3], rmin[3], rmax[3];
             uint32_t left, right;
 #if TRACE_COMPACT
@@ -181,7 +248,9 @@ __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f
             const float4 *tp = reinterpret_cast<const float4 *>(sc.trirecs + slot);
             float4 a = tp[0], b = tp[1], c = tp[2];
             int count = __float_as_int(b.w);
+            FLX_WAVE_TICK(2);
             for (int k = 0;;) {
+                FLX_WAVE_TICK(3);
                 if (STATS) nTri++;
                 float t, u, v;
                 if (moller_trumbore(orig, dir, ld3(a), ld3(b), ld3(c), &t, &u, &v) && t > 0.0f && t < tbest) {
@@ -200,6 +269,8 @@ __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f
 #endif
     }
     return false;
+#endif
+#undef FLX_WAVE_TICK
 }
 
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     float t = FLX_FLT_MAX, u = 0.0f, v = 0.0f;
     int tri = -1;
     uint32_t nInner = 0, nTri = 0;
-    traverse<false, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
+    traverse<false, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri, STATS ? aux.stats + 8 : nullptr);
 
     // commit: shading attributes of the winning triangle (reference: src/bvh.cl:271-279)
     f3 P = mk3(0.0f), N = mk3(0.0f);
@@ -80,9 +80,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     if (STATS) {
         bool hitGeom = matId >= 0 && !(flags & 1u);
         unsigned long long a = nInner, b = nTri, c = hitGeom ? 1ull : 0ull;
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+        uint32_t mx = nInner;                                           // longest ray of the wave (lower bound of the wave's trip count)
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
         uint64_t act = __ballot(true);
         if (lane_id() == (uint32_t)__ffsll((long long)act) - 1u) {
+            atomicAdd(&aux.stats[7], (unsigned long long)mx);
             atomicAdd(&aux.stats[0], (unsigned long long)__popcll(act));
             atomicAdd(&aux.stats[1], a); atomicAdd(&aux.stats[2], b); atomicAdd(&aux.stats[3], c);
         }
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, SHADOW_MIN_WAVES) void k_shadow(State 
     if (p.useAreaLight) { float tl = lenL; occluded = light_quad(p.areaLight, orig, dir, &tl); }
     if (!occluded) {
         float t = lenL, u, v; int tri;
-        occluded = traverse<true, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri);
+        occluded = traverse<true, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri, STATS ? aux.stats + 12 : nullptr);
     }
     st.blocked[gid] = occluded ? 1u : 0u;
 

@@ -19,7 +19,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
-           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
+           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
@@ -206,5 +206,12 @@ class HipContext:
         self._chk(self.L.flx_trace_stats_get(self.h, _p(out)))
         return dict(ext_rays=int(out[0]), ext_inner=int(out[1]), ext_tri=int(out[2]), ext_hits=int(out[3]),
                     shadow_inner=int(out[4]), shadow_tri=int(out[5]), shadow_rays=int(out[6]))
+
+    def wave_stats(self):
+        """Wave-level trip counts of the traversal loops (see flx_trace_stats_get_ex)."""
+        out = np.zeros(16, np.uint64)
+        self._chk(self.L.flx_trace_stats_get_ex(self.h, _p(out)))
+        k = ("outer", "inner", "leaf", "tri")
+        return dict(ext={n: int(out[8 + i]) for i, n in enumerate(k)}, shadow={n: int(out[12 + i]) for i, n in enumerate(k)}, ext_max_inner_sum=int(out[7]))
 
     def set_option(self, name, value): self._chk(self.L.flx_set_option(self.h, name.encode(), int(value)))

@@ -131,6 +131,10 @@ int flx_profile_reset(flx_ctx *ctx);
  * shadow triangle tests, shadow rays}.  Counting launches are not used inside timed regions. */
 int flx_trace_stats_enable(flx_ctx *ctx, int on);
 int flx_trace_stats_get(flx_ctx *ctx, uint64_t *out7);
+/* the same 7 counters + out16[8..11] / [12..15]: wave-level trip counts of the extension / shadow traversal
+ * {outer iterations, inner-node branch executions, leaf branch executions, triangle-loop trips}; SIMD efficiency of
+ * the traversal = lane-level visits / (64 x wave-level trips) */
+int flx_trace_stats_get_ex(flx_ctx *ctx, uint64_t *out16);
 int flx_trace_stats_reset(flx_ctx *ctx);
 
 /* ---- test hooks: path state in the reference's GPUTaskState SoA layout (64 columns x num_tasks
