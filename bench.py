@@ -130,6 +130,11 @@ def main():
     ap.add_argument("--compact-nodes", type=int, default=1)
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--refill-thresh", type=int, default=40)
+    ap.add_argument("--node-layout", type=int, default=1)
+    ap.add_argument("--stream-refill", type=int, default=24)
+    ap.add_argument("--stream-inner-min", type=int, default=24)
+    ap.add_argument("--stream-waves-ext", type=int, default=28)
+    ap.add_argument("--stream-waves-shadow", type=int, default=28)
     args = ap.parse_args()
 
     import torch
@@ -166,6 +171,11 @@ def main():
         c_.set_option("overlap", args.overlap)
         c_.set_option("compact_nodes", args.compact_nodes)
         c_.set_option("refill_thresh", args.refill_thresh)
+        c_.set_option("node_layout", args.node_layout)
+        c_.set_option("stream_refill", args.stream_refill)
+        c_.set_option("stream_inner_min", args.stream_inner_min)
+        c_.set_option("stream_waves_ext", args.stream_waves_ext)
+        c_.set_option("stream_waves_shadow", args.stream_waves_shadow)
         c_.upload_scene(d)
         c_.upload_envmap(env)
         c_.set_partition(rank * C + i, world * C)

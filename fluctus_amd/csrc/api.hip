@@ -13,6 +13,8 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
 void launch_shadow_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
+void launch_extend_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, float4 *, int, int, uint32_t, bool);
+void launch_shadow_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int, int, uint32_t, bool);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
@@ -65,6 +67,11 @@ struct flx_ctx {
     int compact = 1;            // use the 32-byte compact node records when the tree allows it
     int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
     int refillThresh = 40;
+    int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
+    int streamInnerMin = 24;    // trace_mode 2: leave the descent loop when fewer lanes than this descend and leaves are pending
+    int streamRefill = 24;      // trace_mode 2: refill when at least this many lanes are idle
+    int streamWavesExt = 28, streamWavesShadow = 28;   // trace_mode 2: grid = CUs x this many waves
+    float4 *hitraw = nullptr;   // trace_mode 2: {t,u,v,tri} per extension-queue slot
     int numCUs = 256;
     uint32_t *fetch = nullptr;  // 2 x 8 shard counters for the persistent trace kernels
     // owned device allocations
@@ -167,6 +174,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->spill2, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->hitraw, (size_t)num_tasks)) return fail("hipMalloc(hitraw)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->fetch, 16)) return fail("hipMalloc(fetch)", hipErrorOutOfMemory);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     if (dalloc(c, c->fixedAllocs, &c->stats, 16)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
@@ -239,9 +247,38 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         trirecs[s].c = make_float4(t.v2.p.x, t.v2.p.y, t.v2.p.z, 0.0f);
     }
     // 2. inner-node records: both child boxes + refs; DFS numbering of inner nodes only
+    // Record numbering ("sibling pairs"): the vector L1 and the L2 move 128-B lines, a BNode is 64 B.  The two inner children
+    // of a node get the two halves of ONE 128-B-aligned line, allocated when their parent is numbered (pre-order, so a
+    // root-to-leaf path stays roughly contiguous): descending into the nearer child brings the farther child's record
+    // along, and the later pop of that sibling finds its line in L1/L2 instead of missing.  Single inner children are
+    // packed two to a line.  Option node_layout 0 (set before the upload) = plain DFS numbering, for A/B.
     std::vector<int32_t> innerId(nnodes, -1);
-    uint32_t ninner = 0;
-    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) innerId[i] = (int32_t)ninner++;    // reference DFS order
+    uint32_t ninner = 0, nrecords = 0;
+    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) ninner++;
+    const int nodeLayout = c->nodeLayout;
+    if (nodeLayout == 0 || ninner == 0) {
+        for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims == 0) innerId[i] = (int32_t)nrecords++;     // reference DFS order
+    } else {
+        std::vector<uint32_t> todo; todo.reserve(128);
+        innerId[0] = 0; nrecords = 2;                                   // the root's line-mate stays empty
+        int32_t spare = -1;                                             // free half of a line opened for a single inner child
+        todo.push_back(0);
+        while (!todo.empty()) {
+            const uint32_t i = todo.back(); todo.pop_back();
+            const uint32_t l = i + 1, r = nodes[i].iStartOrRight;
+            NEED(c, l < nnodes && r < nnodes, "flx_upload_scene: child index out of range");
+            const bool li = nodes[l].nPrims == 0, ri = nodes[r].nPrims == 0;
+            if (li && ri) { innerId[l] = (int32_t)nrecords; innerId[r] = (int32_t)nrecords + 1; nrecords += 2; }
+            else if (li || ri) {
+                const uint32_t ch = li ? l : r;
+                if (spare >= 0) { innerId[ch] = spare; spare = -1; }
+                else { innerId[ch] = (int32_t)nrecords; spare = (int32_t)nrecords + 1; nrecords += 2; }
+            }
+            if (ri) todo.push_back(r);                                  // left subtree first
+            if (li) todo.push_back(l);
+        }
+        for (size_t i = 0; i < nnodes; i++) NEED(c, nodes[i].nPrims != 0 || innerId[i] >= 0, "flx_upload_scene: inner node unreachable from the root");
+    }
     auto childRef = [&](uint32_t ni, bool &ok) -> uint32_t {
         if (ni >= nnodes) { ok = false; return 0; }
         const flx_node &n = nodes[ni];
@@ -249,9 +286,11 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         if ((size_t)n.iStartOrRight + n.nPrims > nidx) { ok = false; return 0; }
         int cnt = n.nPrims; float fc; memcpy(&fc, &cnt, 4);
         trirecs[n.iStartOrRight].b.w = fc;               // leaf count lives in the run's first record
+        { uint32_t one = 1u; float fl; memcpy(&fl, &one, 4); trirecs[n.iStartOrRight + n.nPrims - 1].c.w = fl; }   // end-of-run flag (trace_mode 3)
         return FLX_LEAF_BIT | n.iStartOrRight;
     };
-    std::vector<BNode> bnodes(ninner ? ninner : 1);
+    std::vector<BNode> bnodes(ninner ? nrecords : 1);
+    memset(bnodes.data(), 0, bnodes.size() * sizeof(BNode));
     bool ok = true;
     if (ninner == 0) {
         // the whole scene is one leaf: synthetic root whose two children are that leaf
@@ -277,8 +316,8 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     // least one child carries the node's own plane bit for bit -- true for any BVH whose boxes are exact unions.
     std::vector<CNode> cnodes;
     {
-        bool compactable = ninner > 0 && ninner <= CREF_INDEX_MASK && nidx <= CREF_INDEX_MASK;
-        if (compactable) cnodes.resize(ninner);
+        bool compactable = ninner > 0 && nrecords <= CREF_INDEX_MASK && nidx <= CREF_INDEX_MASK;
+        if (compactable) { cnodes.resize(nrecords); memset(cnodes.data(), 0, cnodes.size() * sizeof(CNode)); }
         for (size_t i = 0; i < nnodes && compactable; i++) {
             if (nodes[i].nPrims != 0) continue;
             const flx_node &P = nodes[i], &L = nodes[i + 1], &R = nodes[nodes[i].iStartOrRight];
@@ -315,7 +354,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     freeAll(c->sceneAllocs);
     CNode *dC = nullptr;
     BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX;
-    if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size()) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
+    if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size() + 1) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
         dalloc(c, c->sceneAllocs, &dTri, ntris) || dalloc(c, c->sceneAllocs, &dM, nmat) || dalloc(c, c->sceneAllocs, &dD, ntex) || dalloc(c, c->sceneAllocs, &dX, texbytes + 4))
         return 1;
     if (!cnodes.empty()) { if (dalloc(c, c->sceneAllocs, &dC, cnodes.size())) return 1; HIPCHK(c, hipMemcpy(dC, cnodes.data(), cnodes.size() * sizeof(CNode), hipMemcpyHostToDevice)); }
@@ -382,6 +421,7 @@ int flx_wf_extend(flx_ctx *c)
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
+        else if (c->traceMode >= 2) launch_extend_stream(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->hitraw, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesExt), c->traceMode == 3);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -403,6 +443,7 @@ int flx_wf_shadow(flx_ctx *c)
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
         if (c->traceMode == 1) launch_shadow_persistent(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->fetch + 8, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
+        else if (c->traceMode >= 2) launch_shadow_stream(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesShadow), c->traceMode == 3);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -594,7 +635,12 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && (value == 0 || value == 1)) { c->overlap = value; return 0; }
     if (name && strcmp(name, "compact_nodes") == 0 && (value == 0 || value == 1)) { c->compact = value; c->sc.cnodes = value ? c->sc.cnodesAll : nullptr; return 0; }
-    if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 1)) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "trace_mode") == 0 && value >= 0 && value <= 3) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
+    if (name && strcmp(name, "stream_inner_min") == 0 && value >= 1 && value <= 64) { c->streamInnerMin = value; return 0; }
+    if (name && strcmp(name, "stream_refill") == 0 && value >= 1 && value <= 64) { c->streamRefill = value; return 0; }
+    if (name && strcmp(name, "stream_waves_ext") == 0 && value >= 1 && value <= 64) { c->streamWavesExt = value; return 0; }
+    if (name && strcmp(name, "stream_waves_shadow") == 0 && value >= 1 && value <= 64) { c->streamWavesShadow = value; return 0; }
     if (name && strcmp(name, "refill_thresh") == 0 && value >= 1 && value <= 64) { c->refillThresh = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;

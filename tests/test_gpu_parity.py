@@ -18,8 +18,9 @@ pytestmark = pytest.mark.gpu
 TRACE_MODE = {"mode": 1, "thresh": 40, "xcd": 0, "compact": 1}
 
 
-@pytest.fixture(params=[(0, 40, 0, 1), (0, 40, 1, 0), (1, 40, 0, 1), (1, 64, 1, 1), (1, 8, 0, 0)],
-                ids=["thread-per-ray", "thread-per-ray-xcdremap-fullnodes", "persistent-t40", "persistent-t64-xcdremap", "persistent-t8-fullnodes"], autouse=True)
+@pytest.fixture(params=[(0, 40, 0, 1), (0, 40, 1, 0), (1, 40, 0, 1), (1, 64, 1, 1), (1, 8, 0, 0), (2, 24, 0, 1), (2, 1, 0, 1), (2, 64, 0, 0), (3, 24, 0, 1), (3, 1, 0, 1), (3, 64, 0, 0)],
+                ids=["thread-per-ray", "thread-per-ray-xcdremap-fullnodes", "persistent-t40", "persistent-t64-xcdremap", "persistent-t8-fullnodes",
+                     "stream-refill24", "stream-refill1", "stream-refill64", "flow-refill24", "flow-refill1", "flow-refill64"], autouse=True)
 def trace_mode(request):
     TRACE_MODE["mode"], TRACE_MODE["thresh"], TRACE_MODE["xcd"], TRACE_MODE["compact"] = request.param
     yield
@@ -31,6 +32,7 @@ def _ctxs(d, p, n, env=None):
     g, o = HipContext(n), OracleContext(n, threads=8)
     g.set_option("trace_mode", TRACE_MODE["mode"])
     g.set_option("refill_thresh", TRACE_MODE["thresh"])
+    g.set_option("stream_refill", TRACE_MODE["thresh"])
     g.set_option("xcd_remap", TRACE_MODE["xcd"])
     g.set_option("compact_nodes", TRACE_MODE["compact"])
     for c in (g, o):
