@@ -144,7 +144,12 @@ int flx_state_import(flx_ctx *ctx, const float *in_64xN);
 int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
 int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);
 int flx_set_counters(flx_ctx *ctx, const void *in32);
-/* tuning knobs (kernel variants); see DESIGN.md.  Unknown names fail. */
+/* tuning knobs (kernel variants, all bit-identical in their results); see DESIGN.md 4.1.  Unknown names fail.
+ *   trace_mode        0 thread per ray (default) | 1 persistent waves, atomic refill | 2 static-chunk refill, threshold
+ *                     descent | 3 static-chunk refill, unified work items
+ *   overlap           1 (default): flx_wf_shadow directly after flx_wf_extend runs concurrently on a second stream
+ *   node_layout       1 (default) sibling-pair record numbering | 0 DFS numbering; takes effect at the next flx_upload_scene
+ *   compact_nodes, xcd_remap, refill_thresh, stream_refill, stream_inner_min, stream_waves_ext, stream_waves_shadow */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus
