@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--num-tasks", type=int, default=NUM_TASKS)
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
-    ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=2)
     ap.add_argument("--compact-nodes", type=int, default=1)
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--refill-thresh", type=int, default=40)

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 #include <cstdio>
 #include <utility>
 
@@ -41,9 +42,10 @@ struct flx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;              // the shadow kernel runs here, concurrently with the extension kernel
-    hipEvent_t evPreExt = nullptr, evShadow = nullptr;
+    hipEvent_t evPreExt = nullptr, evShadow = nullptr, evPostLogic = nullptr;
     bool overlapOK = false;                     // true between flx_wf_extend and the next enqueue
-    int overlap = 1;
+    bool logicChain = false, logicChainPrev = false;   // only raygen / materials / extend enqueued since flx_wf_logic
+    int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic
     uint32_t *spill2 = nullptr;
     uint32_t numTasks = 0;
     std::string err;
@@ -135,6 +137,10 @@ static int allocFrame(flx_ctx *c)
 
 extern "C" {
 
+// Every entry point that enqueues work or changes device state breaks the two "what came before" chains that let
+// flx_wf_shadow run ahead on the second stream; the few calls that are safe to run ahead of restore them (KEEP_CHAIN).
+#define MUTATES(c) do { (c)->overlapOK = false; (c)->logicChainPrev = (c)->logicChain; (c)->logicChain = false; } while (0)
+#define KEEP_CHAIN(c) do { (c)->logicChain = (c)->logicChainPrev; } while (0)
 const char *flx_last_error(flx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
@@ -151,7 +157,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-    if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
     c->st.numTasks = num_tasks;
     for (int r = 0; r < S_NUM_REC; r++) {
@@ -216,6 +223,7 @@ int flx_destroy(flx_ctx *c)
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->evPreExt) (void)hipEventDestroy(c->evPreExt);
     if (c->evShadow) (void)hipEventDestroy(c->evShadow);
+    if (c->evPostLogic) (void)hipEventDestroy(c->evPostLogic);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -229,6 +237,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
                      const void *nodesv, size_t nnodes, const void *materials, size_t nmat,
                      const void *texdesc, size_t ntex, const uint8_t *texdata, size_t texbytes)
 {
+    MUTATES(c);
     NEED(c, trisv && ntris && indices && nidx && nodesv && nnodes, "flx_upload_scene: empty scene");
     NEED(c, materials && nmat, "flx_upload_scene: at least the default material is required");
     HIPCHK(c, hipSetDevice(c->device));
@@ -373,6 +382,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
 
 int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *prob, const int *alias, const float *pdf)
 {
+    MUTATES(c);
     NEED(c, rgb && prob && alias && pdf && w > 0 && h > 0, "flx_upload_envmap: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
@@ -392,6 +402,7 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
 
 int flx_set_params(flx_ctx *c, const void *p240)
 {
+    MUTATES(c);
     NEED(c, p240, "flx_set_params: null");
     HIPCHK(c, hipSetDevice(c->device));
     memcpy(&c->params, p240, sizeof(flx_render_params));   // kernels receive the struct by value at launch = in-order semantics
@@ -402,20 +413,22 @@ int flx_set_params(flx_ctx *c, const void *p240)
 
 int flx_set_partition(flx_ctx *c, uint32_t rank, uint32_t nranks)
 {
+    MUTATES(c);
     NEED(c, nranks >= 1 && rank < nranks, "flx_set_partition: bad rank");
     c->fr.rank = rank; c->fr.nranks = nranks;
     return c->haveParams ? allocFrame(c) : 0;
 }
 uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 
-#define READY(c) do { (c)->overlapOK = false; NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+#define READY(c) do { MUTATES(c); NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
 int flx_wf_reset(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
-int flx_wf_raygen(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
+    KEEP_CHAIN(c);
     if (c->overlap) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));      // "everything enqueued before the extension kernel"
     if (c->profile) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
@@ -435,10 +448,20 @@ int flx_wf_shadow(flx_ctx *c)
     // order, src/tracer.cpp:250-251) it is launched on a second stream that only waits for the work enqueued BEFORE the
     // extension kernel, so the two traversals share the machine and fill each other's tails; the main stream then waits
     // for it, which keeps the single-in-order-queue semantics for everything that follows.
+    // overlap 2: its inputs are complete when `logic` is (NEE lives there, src/wf_logic.cl:217-302).  What the reference
+    // enqueues between logic and traceShadow -- genRays and the material kernels -- neither writes what the shadow kernel
+    // reads nor reads what it writes: they work on {orig, dir, T, lastBsdf, hit record} of the raygen / material queues,
+    // and a path is never in the raygen queue (terminated) and the shadow queue (continuing) of the same iteration, so
+    // init_path_state's writes to shadowRayBlocked / shadowRayLen touch other paths.  So if ONLY those calls came since
+    // flx_wf_logic, the second stream waits for logic alone and the latency-bound shadow traversal also overlaps the
+    // HBM-bound raygen and material kernels.
     const bool overlapped = c->overlapOK;
+    const bool early = overlapped && c->overlap == 2 && c->logicChain;
     READY(c);
     hipStream_t s = c->stream;
-    if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, c->evPreExt, 0)); }
+    if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, early ? c->evPostLogic : c->evPreExt, 0)); }
+    hipEvent_t earlyStart = nullptr;
+    if (c->profile && early) { earlyStart = getEvent(c); (void)hipEventRecord(earlyStart, s); }
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
@@ -449,18 +472,23 @@ int flx_wf_shadow(flx_ctx *c)
     LAUNCHED(c);
     if (overlapped) { HIPCHK(c, hipEventRecord(c->evShadow, s)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadow, 0)); }
     if (c->profile && overlapped && c->spanStart) {
-        hipEvent_t b = getEvent(c); (void)hipEventRecord(b, c->stream);       // after the join: both traversals done
+        // span of the two traversals: from the earlier start (the shadow kernel's when it ran ahead) to the join
+        hipEvent_t b = getEvent(c); (void)hipEventRecord(b, c->stream);
+        if (earlyStart) { c->eventPool.push_back(c->spanStart); c->spanStart = earlyStart; earlyStart = nullptr; }
         c->events.push_back({FLX_K_TRACE_SPAN, c->spanStart, b}); c->spanStart = nullptr;
     }
+    if (earlyStart) c->eventPool.push_back(earlyStart);
     return 0;
 }
 int flx_wf_logic(flx_ctx *c, int first)
 {
     READY(c);
     { ScopedTimer t(c, FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first); }
-    LAUNCHED(c); return 0;
+    LAUNCHED(c);
+    if (c->overlap == 2) { HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream)); c->logicChain = true; }
+    return 0;
 }
-int flx_wf_materials(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); } LAUNCHED(c); return 0; }
+int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); } LAUNCHED(c); return 0; }
 int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
 // ---- microkernel integrator
@@ -472,6 +500,7 @@ int flx_mk_splat(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr
 int flx_mk_splat_preview(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
 int flx_mk_stats_async(flx_ctx *c, void *out16)
 {
+    MUTATES(c);
     NEED(c, out16, "flx_mk_stats_async: null");
     HIPCHK(c, hipSetDevice(c->device));
     if ((int)c->pendingMk.size() >= c->pinnedSlots) { c->err = "too many outstanding stats reads; call flx_finish"; return 1; }
@@ -480,9 +509,9 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
     c->pendingMk.push_back({out16, slot});
     return 0;
 }
-int flx_mk_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
+int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
-int flx_clear_queues(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+int flx_clear_queues(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
@@ -514,6 +543,7 @@ int flx_finish(flx_ctx *c)
 
 int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 {
+    MUTATES(c);
     NEED(c, npix > 0, "flx_pixel_index_update: zero pixels");
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = (uint32_t)(((uint64_t)c->hostPixelIdx + nnew) % npix);
@@ -524,6 +554,7 @@ int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 }
 int flx_pixel_index_reset(flx_ctx *c)
 {
+    MUTATES(c);
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = 0;
     HIPCHK(c, hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream));
@@ -548,6 +579,7 @@ int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 
 int flx_read_pixels(flx_ctx *c, int which, float *out)
 {
+    MUTATES(c);
     NEED(c, c->fr.pixels && out, "flx_read_pixels: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, which == 0 ? c->fr.pixels : c->fr.preview, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToHost, c->stream));
@@ -556,6 +588,7 @@ int flx_read_pixels(flx_ctx *c, int which, float *out)
 }
 int flx_copy_pixels_to_device(flx_ctx *c, void *dst)
 {
+    MUTATES(c);
     NEED(c, c->fr.pixels && dst, "flx_copy_pixels_to_device: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
@@ -581,11 +614,12 @@ int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int flx_trace_stats_reset(flx_ctx *c) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 128, c->stream)); return 0; }
+int flx_trace_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 128, c->stream)); return 0; }
 
 // ---- test hooks
 int flx_state_export(flx_ctx *c, float *out)
 {
+    MUTATES(c);
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
     HIPCHK(c, hipMalloc((void **)&d, bytes));
@@ -598,6 +632,7 @@ int flx_state_export(flx_ctx *c, float *out)
 }
 int flx_state_import(flx_ctx *c, const float *in)
 {
+    MUTATES(c);
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
     HIPCHK(c, hipMalloc((void **)&d, bytes));
@@ -617,6 +652,7 @@ int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
 }
 int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
 {
+    MUTATES(c);
     NEED(c, q >= 0 && q < FLX_NUM_QUEUES && n <= c->numTasks, "bad queue id / length");
     HIPCHK(c, hipSetDevice(c->device));
     if (n) HIPCHK(c, hipMemcpyAsync(c->qs.q[q], in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -625,6 +661,7 @@ int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
 }
 int flx_set_counters(flx_ctx *c, const void *in32)
 {
+    MUTATES(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->qs.counters, in32, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -633,7 +670,7 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
-    if (name && strcmp(name, "overlap") == 0 && (value == 0 || value == 1)) { c->overlap = value; return 0; }
+    if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
     if (name && strcmp(name, "compact_nodes") == 0 && (value == 0 || value == 1)) { c->compact = value; c->sc.cnodes = value ? c->sc.cnodesAll : nullptr; return 0; }
     if (name && strcmp(name, "trace_mode") == 0 && value >= 0 && value <= 3) { c->traceMode = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
