@@ -93,6 +93,10 @@ class OracleContext:
     def set_partition(self, rank, nranks):
         self.L.orc_set_partition(self.h, C.c_uint32(rank), C.c_uint32(nranks))
 
+    def set_option(self, name, value):
+        """Only "denoiser" (the reference's USE_OPTIX_DENOISER build of the kernels); device tuning knobs do not exist here."""
+        assert self.L.orc_set_option(self.h, name.encode(), int(value)) == 0, name
+
     def wf_reset(self): self.L.orc_wf_reset(self.h)
     def wf_raygen(self): self.L.orc_wf_raygen(self.h)
     def wf_extend(self): self.L.orc_wf_extend(self.h)

@@ -32,6 +32,16 @@ LOGIC_DECL(0) LOGIC_DECL(1) LOGIC_DECL(2) LOGIC_DECL(3) LOGIC_DECL(4) LOGIC_DECL
 LOGIC_DECL(8) LOGIC_DECL(9) LOGIC_DECL(10) LOGIC_DECL(11) LOGIC_DECL(12) LOGIC_DECL(13) LOGIC_DECL(14) LOGIC_DECL(15)
 LOGIC_DECL(16) LOGIC_DECL(17) LOGIC_DECL(18) LOGIC_DECL(19) LOGIC_DECL(20) LOGIC_DECL(21) LOGIC_DECL(22) LOGIC_DECL(23)
 LOGIC_DECL(24) LOGIC_DECL(25) LOGIC_DECL(26) LOGIC_DECL(27) LOGIC_DECL(28) LOGIC_DECL(29) LOGIC_DECL(30) LOGIC_DECL(31)
+#undef LOGIC_DECL
+#define LOGIC_DECL(n) void logic_d##n(float *, float *, float *, float *, void *, uint *, uint *, uint *, uint *, uint *, uint *, uint *, uint *, void *, void *, uint *, const ref_image *, float *, int *, float *, void *, uint8_t *, void *, void *, uint, uint);
+LOGIC_DECL(0) LOGIC_DECL(1) LOGIC_DECL(2) LOGIC_DECL(3) LOGIC_DECL(4) LOGIC_DECL(5) LOGIC_DECL(6) LOGIC_DECL(7)
+LOGIC_DECL(8) LOGIC_DECL(9) LOGIC_DECL(10) LOGIC_DECL(11) LOGIC_DECL(12) LOGIC_DECL(13) LOGIC_DECL(14) LOGIC_DECL(15)
+LOGIC_DECL(16) LOGIC_DECL(17) LOGIC_DECL(18) LOGIC_DECL(19) LOGIC_DECL(20) LOGIC_DECL(21) LOGIC_DECL(22) LOGIC_DECL(23)
+LOGIC_DECL(24) LOGIC_DECL(25) LOGIC_DECL(26) LOGIC_DECL(27) LOGIC_DECL(28) LOGIC_DECL(29) LOGIC_DECL(30) LOGIC_DECL(31)
+static const logic_fn logic_variants_den[32] = {                    /* built with -DUSE_OPTIX_DENOISER */
+    logic_d0, logic_d1, logic_d2, logic_d3, logic_d4, logic_d5, logic_d6, logic_d7, logic_d8, logic_d9, logic_d10, logic_d11,
+    logic_d12, logic_d13, logic_d14, logic_d15, logic_d16, logic_d17, logic_d18, logic_d19, logic_d20, logic_d21, logic_d22,
+    logic_d23, logic_d24, logic_d25, logic_d26, logic_d27, logic_d28, logic_d29, logic_d30, logic_d31};
 static const logic_fn logic_variants[32] = {
     logic_v0, logic_v1, logic_v2, logic_v3, logic_v4, logic_v5, logic_v6, logic_v7, logic_v8, logic_v9, logic_v10, logic_v11,
     logic_v12, logic_v13, logic_v14, logic_v15, logic_v16, logic_v17, logic_v18, logic_v19, logic_v20, logic_v21, logic_v22,
@@ -53,6 +63,12 @@ void sampleBsdf(float *tasks, float *denAlbedo, void *materials, uint8_t *texDat
 void splat(float *tasks, float *pixels, void *params, void *stats, uint numTasks);
 void splatPreview(float *tasks, float *pixels, void *params, uint numTasks);
 void process(float *pixelsRaw, float *denAlbedo, float *denNormal, float *pixelsPreview, float *denAlbedoGL, float *denNormalGL, void *params, uint numTasks);
+/* -DUSE_OPTIX_DENOISER builds of the kernels that write / resolve the denoiser feature buffers */
+void process_d(float *pixelsRaw, float *denAlbedo, float *denNormal, float *pixelsPreview, float *denAlbedoGL, float *denNormalGL, void *params, uint numTasks);
+void nextVertex_d(float *tasks, void *materials, uint8_t *texData, void *textures, float *denNormal, void *tris, void *nodes, uint *indices, void *params,
+                  void *stats, const ref_image *envMap, float *pdfTable, uint numTasks);
+void sampleBsdf_d(float *tasks, float *denAlbedo, void *materials, uint8_t *texData, void *textures, const ref_image *envMap, float *probTable, int *aliasTable,
+                  float *pdfTable, void *tris, void *nodes, uint *indices, void *params, void *stats, uint numTasks);
 
 typedef struct {
     uint numTasks;
@@ -61,7 +77,8 @@ typedef struct {
     flx_queue_counters counters __attribute__((aligned(64)));
     uint currPixelIdx, hostPixelIdx;
     flx_render_params params __attribute__((aligned(64)));   /* kernels load float3 members with aligned 16-byte moves */
-    float *pixels, *preview, *denAlbedo, *denNormal;
+    float *pixels, *preview, *denAlbedo, *denNormal, *denAlbedoGL, *denNormalGL;
+    int denoiser;
     size_t npix;
     void *tris; size_t ntris; uint *indices; size_t nidx; void *nodes; size_t nnodes;
     void *materials; size_t nmat; void *texdesc; size_t ntex; uint8_t *texdata; size_t texbytes;
@@ -89,7 +106,7 @@ int ref_create(uint32_t num_tasks, ref_ctx **out)
 int ref_destroy(ref_ctx *c)
 {
     free(c->tasks); for (int q = 0; q < FLX_NUM_QUEUES; q++) free(c->queues[q]);
-    free(c->pixels); free(c->preview); free(c->denAlbedo); free(c->denNormal);
+    free(c->pixels); free(c->preview); free(c->denAlbedo); free(c->denNormal); free(c->denAlbedoGL); free(c->denNormalGL);
     free(c->tris); free(c->indices); free(c->nodes); free(c->materials); free(c->texdesc); free(c->texdata);
     free(c->envRGBA); free(c->prob); free(c->pdf); free(c->alias); free(c);
     return 0;
@@ -118,9 +135,10 @@ int ref_set_params(ref_ctx *c, const void *p240)
     memcpy(&c->params, p240, 240);
     size_t npix = (size_t)c->params.width * c->params.height;
     if (npix != c->npix) {
-        free(c->pixels); free(c->preview); free(c->denAlbedo); free(c->denNormal);
+        free(c->pixels); free(c->preview); free(c->denAlbedo); free(c->denNormal); free(c->denAlbedoGL); free(c->denNormalGL);
         c->pixels = (float *)calloc(npix, 16); c->preview = (float *)calloc(npix, 16);
         c->denAlbedo = (float *)calloc(npix, 16); c->denNormal = (float *)calloc(npix, 16);
+        c->denAlbedoGL = (float *)calloc(npix, 16); c->denNormalGL = (float *)calloc(npix, 16);
         c->npix = npix;
     }
     return 0;
@@ -153,7 +171,7 @@ int ref_wf_logic(ref_ctx *c, int first)
 {
     const flx_render_params *p = &c->params;      /* build flags: kernel_impl.hpp:49-67 */
     int v = (p->useAreaLight ? 1 : 0) | (p->useEnvMap ? 2 : 0) | (p->sampleExpl ? 4 : 0) | (p->sampleImpl ? 8 : 0) | (!p->wfSeparateQueues ? 16 : 0);
-    logic_fn f = logic_variants[v];
+    logic_fn f = c->denoiser ? logic_variants_den[v] : logic_variants[v];
     size_t n = ((size_t)(c->numTasks - 1) / 32 + 1) * 32;            /* clcontext.cpp:792 */
     RANGE(n, f(c->tasks, c->pixels, c->denNormal, c->denAlbedo, &c->counters, c->queues[FLX_Q_EXTENSION], c->queues[FLX_Q_SHADOW],
                c->queues[FLX_Q_RAYGEN], c->queues[FLX_Q_DIFFUSE], c->queues[FLX_Q_GLOSSY], c->queues[FLX_Q_GGX_REFL], c->queues[FLX_Q_GGX_REFR],
@@ -176,7 +194,8 @@ int ref_wf_materials(ref_ctx *c)
 }
 int ref_postprocess(ref_ctx *c)
 {
-    RANGE(c->npix, process(c->pixels, c->denAlbedo, c->denNormal, c->preview, c->denAlbedo, c->denNormal, &c->params, c->numTasks));
+    if (c->denoiser) { RANGE(c->npix, process_d(c->pixels, c->denAlbedo, c->denNormal, c->preview, c->denAlbedoGL, c->denNormalGL, &c->params, c->numTasks)); }
+    else { RANGE(c->npix, process(c->pixels, c->denAlbedo, c->denNormal, c->preview, c->denAlbedoGL, c->denNormalGL, &c->params, c->numTasks)); }
     return 0;
 }
 int ref_clear_queues(ref_ctx *c) { memset(&c->counters, 0, 32); return 0; }
@@ -184,7 +203,14 @@ int ref_get_counters(ref_ctx *c, void *out32) { memcpy(out32, &c->counters, 32);
 int ref_set_counters(ref_ctx *c, const void *in32) { memcpy(&c->counters, in32, 32); return 0; }
 int ref_pixel_index_update(ref_ctx *c, uint32_t npix, uint32_t nnew) { c->hostPixelIdx = (c->hostPixelIdx + nnew) % npix; c->currPixelIdx = c->hostPixelIdx; return 0; }
 int ref_pixel_index_reset(ref_ctx *c) { c->hostPixelIdx = 0; c->currPixelIdx = 0; return 0; }
-int ref_read_pixels(ref_ctx *c, int which, float *out) { memcpy(out, which == 0 ? c->pixels : c->preview, c->npix * 16); return 0; }
+int ref_read_pixels(ref_ctx *c, int which, float *out)
+{
+    const float *src[6] = {c->pixels, c->preview, c->denAlbedoGL, c->denNormalGL, c->denAlbedo, c->denNormal};
+    if (which < 0 || which > 5) return 1;
+    memcpy(out, src[which], c->npix * 16);
+    return 0;
+}
+int ref_set_option(ref_ctx *c, const char *name, int value) { if (name && strcmp(name, "denoiser") == 0) { c->denoiser = value != 0; return 0; } return 1; }
 int ref_state_export(ref_ctx *c, float *out) { memcpy(out, c->tasks, (size_t)FLX_NUM_COLS * c->numTasks * 4); return 0; }
 int ref_state_import(ref_ctx *c, const float *in) { memcpy(c->tasks, in, (size_t)FLX_NUM_COLS * c->numTasks * 4); return 0; }
 int ref_queue_read(ref_ctx *c, int q, uint32_t *out) { memcpy(out, c->queues[q], (size_t)c->numTasks * 4); return 0; }
@@ -195,13 +221,16 @@ int ref_mk_reset(ref_ctx *c) { RANGE(c->npix, mk_reset(c->tasks, c->pixels, c->d
 int ref_mk_raygen(ref_ctx *c) { RANGE(c->numTasks, genCameraRays(c->tasks, &c->params, c->numTasks)); return 0; }
 int ref_mk_next_vertex(ref_ctx *c)
 {
-    RANGE(c->numTasks, nextVertex(c->tasks, c->materials, c->texdata, c->texdesc, c->denNormal, c->tris, c->nodes, c->indices, &c->params, c->mkStats, &c->env, c->pdf, c->numTasks));
+    if (c->denoiser) { RANGE(c->numTasks, nextVertex_d(c->tasks, c->materials, c->texdata, c->texdesc, c->denNormal, c->tris, c->nodes, c->indices, &c->params, c->mkStats, &c->env, c->pdf, c->numTasks)); }
+    else { RANGE(c->numTasks, nextVertex(c->tasks, c->materials, c->texdata, c->texdesc, c->denNormal, c->tris, c->nodes, c->indices, &c->params, c->mkStats, &c->env, c->pdf, c->numTasks)); }
     return 0;
 }
 int ref_mk_sample_bsdf(ref_ctx *c)
 {
-    RANGE(c->numTasks, sampleBsdf(c->tasks, c->denAlbedo, c->materials, c->texdata, c->texdesc, &c->env, c->prob, c->alias, c->pdf, c->tris, c->nodes, c->indices,
-                                  &c->params, c->mkStats, c->numTasks));
+    if (c->denoiser) { RANGE(c->numTasks, sampleBsdf_d(c->tasks, c->denAlbedo, c->materials, c->texdata, c->texdesc, &c->env, c->prob, c->alias, c->pdf, c->tris, c->nodes, c->indices,
+                                                       &c->params, c->mkStats, c->numTasks)); }
+    else { RANGE(c->numTasks, sampleBsdf(c->tasks, c->denAlbedo, c->materials, c->texdata, c->texdesc, &c->env, c->prob, c->alias, c->pdf, c->tris, c->nodes, c->indices,
+                                         &c->params, c->mkStats, c->numTasks)); }
     return 0;
 }
 int ref_mk_splat(ref_ctx *c) { RANGE(c->npix, splat(c->tasks, c->pixels, &c->params, c->mkStats, c->numTasks)); return 0; }

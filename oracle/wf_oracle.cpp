@@ -50,6 +50,9 @@ struct Ctx {
     flx_render_params params {};
     std::vector<float> pixels;            /* float4 per pixel */
     std::vector<float> preview;
+    /* denoiser feature buffers (reference: USE_OPTIX_DENOISER; clcontext.cpp:337-338): accumulators + normalised outputs */
+    bool denoiser = false;
+    std::vector<float> aovAlbedo, aovNormal, aovAlbedoOut, aovNormalOut;
     /* scene */
     std::vector<flx_triangle> tris;
     std::vector<uint32_t> indices;
@@ -810,6 +813,26 @@ float bxdfPdf(Ctx &c, const Hit &hit, const flx_material &mat, bool backface, f3
 /* kernels                                                                   */
 /* ------------------------------------------------------------------------ */
 
+/* add_float4 (utils.cl:341-358) on a host buffer */
+inline void addFloat4(float *px, f3 v, float w, bool atomic)
+{
+    if (!atomic) { px[0] += v.x; px[1] += v.y; px[2] += v.z; px[3] += w; return; }
+#pragma omp atomic
+    px[0] += v.x;
+#pragma omp atomic
+    px[1] += v.y;
+#pragma omp atomic
+    px[2] += v.z;
+#pragma omp atomic
+    px[3] += w;
+}
+/* first-hit normal in camera space: rotation rows right, up, -dir (wf_logic.cl:189-196, mk_next_vertex.cl:63-67) */
+inline f3 cameraSpaceNormal(const flx_render_params &p, f3 N)
+{
+    f3 r1 = V(p.camera.right), r2 = V(p.camera.up), r3 = V(p.camera.dir) * -1.0f;
+    return mk3(dot(r1, N), dot(r2, N), dot(r3, N));
+}
+
 /* reference: wf_reset.cl:5-66; launch range clcontext.cpp:765-770 */
 void k_reset(Ctx &c)
 {
@@ -817,7 +840,11 @@ void k_reset(Ctx &c)
     uint32_t npix = p.width * p.height;
     uint32_t n = std::max(c.numTasks, npix);
     for (uint32_t gid = 0; gid < n; gid++) {
-        if (gid < npix) { float *px = &c.pixels[(size_t)gid * 4]; px[0] = px[1] = px[2] = px[3] = 0.0f; }
+        if (gid < npix) {
+            float *px = &c.pixels[(size_t)gid * 4]; px[0] = px[1] = px[2] = px[3] = 0.0f;
+            float *nr = &c.aovNormal[(size_t)gid * 4]; nr[0] = nr[1] = nr[2] = nr[3] = 0.0f;             /* wf_reset.cl:22 */
+            float *al = &c.aovAlbedo[(size_t)gid * 4]; al[0] = al[1] = al[2] = 0.1f; al[3] = 0.0f;       /* wf_reset.cl:23-24 */
+        }
         if (gid >= c.numTasks) continue;
         W3(c, FLX_COL_EI, gid, mk3(0.0f));
         W3(c, FLX_COL_T, gid, mk3(1.0f));
@@ -1088,6 +1115,18 @@ void k_logic(Ctx &c, int firstIteration)
         if (backface) hit.N = hit.N * -1.0f;
         f3 orig = hit.P - 1e-3f * rayDir;
 
+        /* :186-209 denoiser features (USE_OPTIX_DENOISER) */
+        if (c.denoiser) {
+            uint32_t pixIdx = U(c, FLX_COL_PIXEL_INDEX, gid);
+            if (len == 1) addFloat4(&c.aovNormal[(size_t)pixIdx * 4], cameraSpaceNormal(p, hit.N), 1.0f, nthr > 1);
+            bool isDiffuse = !FLX_BXDF_IS_SINGULAR(mat.type);
+            if (isDiffuse && !U(c, FLX_COL_FIRST_DIFFUSE, gid)) {
+                U(c, FLX_COL_FIRST_DIFFUSE, gid) = 1;
+                f3 albedo = matGetFloat3(c, V(mat.Kd), hit.uv, mat.map_Kd);                                /* not gamma-corrected */
+                addFloat4(&c.aovAlbedo[(size_t)pixIdx * 4], albedo, 1.0f, nthr > 1);
+            }
+        }
+
         /* :212-213 */
         writeHit(c, gid, hit);
         U(c, FLX_COL_BACKFACE, gid) = backface ? 1u : 0u;
@@ -1219,6 +1258,8 @@ void k_mk_reset(Ctx &c)
     uint32_t limit = mkLimit(c);
     for (uint32_t gid = 0; gid < limit; gid++) {
         float *px = &c.pixels[(size_t)gid * 4]; px[0] = px[1] = px[2] = px[3] = 0.0f;
+        float *nr = &c.aovNormal[(size_t)gid * 4]; nr[0] = nr[1] = nr[2] = nr[3] = 0.0f;                 /* mk_reset.cl:24-25 */
+        float *al = &c.aovAlbedo[(size_t)gid * 4]; al[0] = al[1] = al[2] = 0.1f; al[3] = 0.0f;
         I(c, FLX_COL_PHASE, gid) = MK_GENERATE_CAMERA_RAY;
         W3(c, FLX_COL_EI, gid, mk3(0.0f)); W3(c, FLX_COL_T, gid, mk3(1.0f));
         U(c, FLX_COL_PATH_LEN, gid) = 0; U(c, FLX_COL_LAST_SPECULAR, gid) = 1; F(c, FLX_COL_LAST_PDF_W, gid) = 1.0f;
@@ -1274,6 +1315,7 @@ void k_mk_next_vertex(Ctx &c)
         if (len == 0) prim++; else ext++;
         len += 1;
         U(c, FLX_COL_PATH_LEN, gid) = len;
+        if (c.denoiser && len == 1) addFloat4(&c.aovNormal[(size_t)gid * 4], cameraSpaceNormal(p, hit.N), 1.0f, false);   /* mk_next_vertex.cl:59-69 */
         if (hit.i < 0) {
             f3 bg = mk3(0.0f);
             if (p.useEnvMap && (len == 1 || p.sampleImpl)) bg = evalEnvMapDir(c, rayDir) * p.envMapStrength;
@@ -1326,6 +1368,10 @@ void k_mk_sample_bsdf(Ctx &c)
         bool backface = dot(hit.N, rayDir) > 0.0f;
         if (backface) hit.N = hit.N * -1.0f;
         f3 orig = hit.P - 1e-3f * rayDir;
+        if (c.denoiser && !FLX_BXDF_IS_SINGULAR(mat.type) && !U(c, FLX_COL_FIRST_DIFFUSE, gid)) {             /* mk_sample_bsdf.cl:56-66 */
+            U(c, FLX_COL_FIRST_DIFFUSE, gid) = 1;
+            addFloat4(&c.aovAlbedo[(size_t)gid * 4], matGetFloat3(c, V(mat.Kd), hit.uv, mat.map_Kd), 1.0f, false);
+        }
         uint64_t a = 0, b = 0;
         if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {
             const float lightPickProb = 1.0f;
@@ -1451,6 +1497,14 @@ void k_postprocess(Ctx &c)
         col = pow3(col, 1.0f / 2.2f);
         float *out = &c.preview[(size_t)gid * 4];
         out[0] = col.x; out[1] = col.y; out[2] = col.z; out[3] = w;
+        if (c.denoiser) {                                                   /* mk_postprocess.cl:49-54 */
+            for (int which = 0; which < 2; which++) {
+                const float *a = which ? &c.aovAlbedo[(size_t)gid * 4] : &c.aovNormal[(size_t)gid * 4];
+                float *o = which ? &c.aovAlbedoOut[(size_t)gid * 4] : &c.aovNormalOut[(size_t)gid * 4];
+                const bool nrm = a[3] > 1.0f;
+                for (int k = 0; k < 4; k++) o[k] = nrm ? a[k] / a[3] : a[k];
+            }
+        }
     }
 }
 
@@ -1513,7 +1567,10 @@ int orc_set_params(orc_ctx *p, const void *params240)
     Ctx &c = CTX(p);
     memcpy(&c.params, params240, sizeof(flx_render_params));
     size_t npix = (size_t)c.params.width * c.params.height;
-    if (c.pixels.size() != npix * 4) { c.pixels.assign(npix * 4, 0.0f); c.preview.assign(npix * 4, 0.0f); }
+    if (c.pixels.size() != npix * 4) {
+        c.pixels.assign(npix * 4, 0.0f); c.preview.assign(npix * 4, 0.0f);
+        c.aovAlbedo.assign(npix * 4, 0.0f); c.aovNormal.assign(npix * 4, 0.0f); c.aovAlbedoOut.assign(npix * 4, 0.0f); c.aovNormalOut.assign(npix * 4, 0.0f);
+    }
     return 0;
 }
 int orc_set_partition(orc_ctx *p, uint32_t rank, uint32_t nranks) { CTX(p).rank = rank; CTX(p).nranks = nranks; return 0; }
@@ -1548,9 +1605,15 @@ int orc_pixel_index_reset(orc_ctx *p) { CTX(p).hostPixelIdx = 0; CTX(p).currPixe
 int orc_read_pixels(orc_ctx *p, int which, float *out)
 {
     Ctx &c = CTX(p);
-    const std::vector<float> &src = which == 0 ? c.pixels : c.preview;
-    memcpy(out, src.data(), src.size() * sizeof(float));
+    const std::vector<float> *srcs[6] = {&c.pixels, &c.preview, &c.aovAlbedoOut, &c.aovNormalOut, &c.aovAlbedo, &c.aovNormal};
+    if (which < 0 || which > 5) return 1;
+    memcpy(out, srcs[which]->data(), srcs[which]->size() * sizeof(float));
     return 0;
+}
+int orc_set_option(orc_ctx *p, const char *name, int value)
+{
+    if (name && strcmp(name, "denoiser") == 0) { CTX(p).denoiser = value != 0; return 0; }
+    return 1;
 }
 int orc_state_export(orc_ctx *p, float *out) { Ctx &c = CTX(p); memcpy(out, c.state.data(), c.state.size() * 4); return 0; }
 int orc_state_import(orc_ctx *p, const float *in) { Ctx &c = CTX(p); memcpy(c.state.data(), in, c.state.size() * 4); return 0; }

@@ -200,3 +200,73 @@ def test_microkernel_integrator_lockstep(area, env, expl, impl, roulette):
         assert sa[3] == 3 * n and sa[0] == 3 * n
     a.mk_splat_preview(); b.mk_splat_preview()
     assert np.allclose(a.read_pixels(0), b.read_pixels(0), rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------- denoiser feature buffers
+def _aov_close(a, b, name):
+    for which, tag in ((4, "albedo accumulator"), (5, "normal accumulator")):
+        xa, xb = a.read_pixels(which), b.read_pixels(which)
+        assert np.array_equal(xa[:, 3], xb[:, 3]), f"{name}: {tag} counts differ"
+        assert np.allclose(xa, xb, rtol=1e-4, atol=1e-5), f"{name}: {tag}"
+
+
+@pytest.mark.parametrize("sep", [0, 1])
+def test_denoiser_features_wavefront(sep):
+    """The reference's USE_OPTIX_DENOISER build of `logic` / `process` (wf_logic.cl:186-209, mk_postprocess.cl:49-54) against
+    the oracle's `denoiser` option, in lockstep: first-hit camera-space normals and first-diffuse-hit albedo per pixel."""
+    d = common.mixed_material_scene()
+    w, h, n = 48, 32, 4096
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, wfSeparateQueues=sep)
+    a, b = _pair(d, p, n, env=host.synthetic_sky(64, 32))
+    for c in (a, b):
+        c.set_option("denoiser", 1)
+        driver.reset_renderer(c)
+    al = a.read_pixels(4)
+    assert np.array_equal(al, b.read_pixels(4)) and np.allclose(al, [0.1, 0.1, 0.1, 0.0])      # wf_reset.cl:23-24
+    for it in range(10):
+        _step(a, b, f"it{it} logic", lambda c: c.wf_logic(False), 1e-4, 1e-5)
+        _aov_close(a, b, f"it{it}")
+        _step(a, b, f"it{it} raygen", lambda c: c.wf_raygen(), 1e-4, 1e-5)
+        _step(a, b, f"it{it} materials", lambda c: c.wf_materials(), 2e-3, 1e-5, undefined_pdfw=True)
+        cnt = a.get_counters().copy()
+        _step(a, b, f"it{it} extend", lambda c: c.wf_extend(), 1e-4, 1e-5)
+        _step(a, b, f"it{it} shadow", lambda c: c.wf_shadow(), 1e-4, 1e-5)
+        for c in (a, b):
+            c.clear_queues(); c.pixel_index_update(w * h, int(cnt[0]))
+    na, aa = a.read_pixels(5), a.read_pixels(4)
+    assert na[:, 3].sum() > 0 and aa[:, 3].sum() > 0 and aa[:, 3].sum() <= na[:, 3].sum()   # every path: one normal, at most one albedo
+    for c in (a, b):
+        c.postprocess()
+    for which in (2, 3):
+        assert np.allclose(a.read_pixels(which), b.read_pixels(which), rtol=1e-4, atol=1e-5)
+    nrm = a.read_pixels(3)
+    done = nrm[:, 3] == 1.0                                           # resolved: sums divided by the count
+    assert done.any() and (np.linalg.norm(nrm[done, :3], axis=1) <= 1.0 + 1e-4).all()
+
+
+def test_denoiser_features_microkernel():
+    """mk_next_vertex.cl:59-69, mk_sample_bsdf.cl:56-66, mk_reset.cl:24-25 with USE_OPTIX_DENOISER vs the oracle."""
+    d = common.mixed_material_scene()
+    w, h = 48, 32
+    n = w * h
+    p = common.scene_params(d, w, h, maxBounces=4, useAreaLight=1, useEnvMap=1)
+    from oracle.binding import RefContext
+    a, b = OracleContext(n), RefContext(n)
+    e = host.synthetic_sky(64, 32)
+    for c in (a, b):
+        c.upload_scene(d); c.upload_envmap(e); c.set_params(p); c.set_option("denoiser", 1)
+        c.mk_reset()
+    for spp in range(3):
+        _mk_step(a, b, "raygen", MK_PHASES[0][1], RTOL, ATOL)
+        for bounce in range(int(p["maxBounces"]) + 1):
+            _mk_step(a, b, "next_vertex", MK_PHASES[1][1], 1e-4, 1e-5)
+            _aov_close(a, b, "next_vertex")
+            _mk_step(a, b, "sample_bsdf", MK_PHASES[2][1], 1e-3, 1e-5)
+            _aov_close(a, b, "sample_bsdf")
+        b.state_import(a.state_export())
+        a.mk_splat(); b.mk_splat()
+    assert (a.read_pixels(5)[:, 3] == 3).all()                       # one first-hit normal per pixel per pass
+    for c in (a, b):
+        c.postprocess()
+    for which in (2, 3):
+        assert np.allclose(a.read_pixels(which), b.read_pixels(which), rtol=1e-4, atol=1e-5)
