@@ -25,8 +25,8 @@ void launch_state_export(hipStream_t, const State &, float *);
 void launch_state_import(hipStream_t, const State &, const float *);
 void launch_mk_reset(hipStream_t, const State &, const Frame &, const flx_render_params &);
 void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
-void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *);
-void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *);
+void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
+void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
 void launch_mk_splat(hipStream_t, const State &, const Frame &, const flx_render_params &, uint32_t *, int);
 void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t);
 }
@@ -69,6 +69,8 @@ struct flx_ctx {
     int compact = 1;            // use the 32-byte compact node records when the tree allows it
     int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
     int refillThresh = 40;
+    int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
+    std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
     int streamInnerMin = 24;    // trace_mode 2: leave the descent loop when fewer lanes than this descend and leaves are pending
     int streamRefill = 24;      // trace_mode 2: refill when at least this many lanes are idle
@@ -121,6 +123,22 @@ static uint32_t localPixels(const flx_ctx *c)
     return (npix - c->fr.rank + c->fr.nranks - 1) / c->fr.nranks;
 }
 
+// denoiser feature buffers (4 x float4 per local pixel) exist only while the option is on
+static int allocAov(flx_ctx *c)
+{
+    freeAll(c->aovAllocs);
+    c->fr.aovAlbedo = c->fr.aovNormal = c->fr.aovAlbedoOut = c->fr.aovNormalOut = nullptr;
+    if (!c->denoiser || !c->fr.localPixels) return 0;
+    const size_t n = (size_t)c->fr.localPixels * 4;
+    float *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+        HIPCHK(c, dalloc(c, c->aovAllocs, &buf[i], n) ? hipErrorOutOfMemory : hipSuccess);
+        HIPCHK(c, hipMemsetAsync(buf[i], 0, n * 4, c->stream));
+    }
+    c->fr.aovAlbedo = buf[0]; c->fr.aovNormal = buf[1]; c->fr.aovAlbedoOut = buf[2]; c->fr.aovNormalOut = buf[3];
+    return 0;
+}
+
 static int allocFrame(flx_ctx *c)
 {
     uint32_t lp = localPixels(c);
@@ -132,7 +150,7 @@ static int allocFrame(flx_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->fr.pixels, 0, (size_t)lp * 16, c->stream));
     HIPCHK(c, hipMemsetAsync(c->fr.preview, 0, (size_t)lp * 16, c->stream));
     c->fr.localPixels = lp;
-    return 0;
+    return allocAov(c);
 }
 
 extern "C" {
@@ -214,7 +232,7 @@ int flx_destroy(flx_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    freeAll(c->sceneAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->fixedAllocs);
+    freeAll(c->sceneAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->aovAllocs); freeAll(c->fixedAllocs);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
     if (c->pinnedMk) (void)hipHostFree(c->pinnedMk);
@@ -494,8 +512,8 @@ int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS
 // ---- microkernel integrator
 int flx_mk_reset(flx_ctx *c) { READY(c); launch_mk_reset(c->stream, c->st, c->fr, c->params); LAUNCHED(c); return 0; }
 int flx_mk_raygen(flx_ctx *c) { READY(c); launch_mk_raygen(c->stream, c->st, c->params); LAUNCHED(c); return 0; }
-int flx_mk_next_vertex(flx_ctx *c) { READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
-int flx_mk_sample_bsdf(flx_ctx *c) { READY(c); launch_mk_sample_bsdf(c->stream, c->st, c->sc, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_next_vertex(flx_ctx *c) { READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_sample_bsdf(flx_ctx *c) { READY(c); launch_mk_sample_bsdf(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
 int flx_mk_splat(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 0); LAUNCHED(c); return 0; }
 int flx_mk_splat_preview(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
 int flx_mk_stats_async(flx_ctx *c, void *out16)
@@ -582,7 +600,10 @@ int flx_read_pixels(flx_ctx *c, int which, float *out)
     MUTATES(c);
     NEED(c, c->fr.pixels && out, "flx_read_pixels: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(out, which == 0 ? c->fr.pixels : c->fr.preview, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToHost, c->stream));
+    NEED(c, which >= 0 && which <= 5, "flx_read_pixels: which must be 0..5");
+    const float *src[6] = {c->fr.pixels, c->fr.preview, c->fr.aovAlbedoOut, c->fr.aovNormalOut, c->fr.aovAlbedo, c->fr.aovNormal};
+    NEED(c, src[which], "flx_read_pixels: the denoiser feature buffers need flx_set_option(ctx, \"denoiser\", 1)");
+    HIPCHK(c, hipMemcpyAsync(out, src[which], (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -673,6 +694,11 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
     if (name && strcmp(name, "compact_nodes") == 0 && (value == 0 || value == 1)) { c->compact = value; c->sc.cnodes = value ? c->sc.cnodesAll : nullptr; return 0; }
     if (name && strcmp(name, "trace_mode") == 0 && value >= 0 && value <= 3) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "denoiser") == 0 && (value == 0 || value == 1)) {
+        MUTATES(c);
+        if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
+        return 0;
+    }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     if (name && strcmp(name, "stream_inner_min") == 0 && value >= 1 && value <= 64) { c->streamInnerMin = value; return 0; }
     if (name && strcmp(name, "stream_refill") == 0 && value >= 1 && value <= 64) { c->streamRefill = value; return 0; }

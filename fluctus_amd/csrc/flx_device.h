@@ -98,6 +98,9 @@ struct Scene {
 struct Frame {                    // framebuffers + cursor + partition
     float *pixels;                // float4 per local pixel (rgb sum, sample count)
     float *preview;
+    // denoiser feature buffers (reference: USE_OPTIX_DENOISER build; src/clcontext.cpp:337-338): float4 per local pixel,
+    // accumulators + the resolved outputs of `process`; nullptr while the option is off
+    float *aovAlbedo, *aovNormal, *aovAlbedoOut, *aovNormalOut;
     uint32_t *currPixelIdx;       // device copy of the pixel cursor
     uint32_t rank, nranks;
     uint32_t localPixels;
@@ -107,6 +110,12 @@ __device__ __forceinline__ f3 ld3(const float4 &v) { return mk3(v.x, v.y, v.z); 
 __device__ __forceinline__ float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 __device__ __forceinline__ float4 mk4u(f3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 __device__ __forceinline__ f3 V(const flx_vec3 &v) { return mk3(v.x, v.y, v.z); }
+// first-hit normal in camera space: rotation rows right, up, -dir (src/wf_logic.cl:189-196, src/mk_next_vertex.cl:63-67)
+__device__ __forceinline__ f3 camera_space_normal(const flx_render_params &p, f3 N)
+{
+    const f3 r1 = V(p.camera.right), r2 = V(p.camera.up), r3 = V(p.camera.dir) * -1.0f;
+    return mk3(dot(r1, N), dot(r2, N), dot(r3, N));
+}
 
 // Path-state accessors.  Every kernel streams the state exactly once per launch, while the BVH is re-read constantly;
 // FLX_NT marks state loads (bit 0) / stores (bit 1) non-temporal so they do not evict the tree from L2 / Infinity Cache.

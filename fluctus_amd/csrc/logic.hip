@@ -136,6 +136,20 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             if (backface) hitN = hitN * -1.0f;
             const f3 hitP = ld3(rd4(st.rec[S_HITP] + gid));
             const f3 orig = hitP - 1e-3f * rayDir;
+            if (fr.aovNormal) {                                       // denoiser features, :186-209
+                const uint32_t pixIdx = __float_as_uint(ei4.w);
+                if (len == 1u) {
+                    const f3 n = camera_space_normal(p, hitN);
+                    float *px = fr.aovNormal + (size_t)pixIdx * 4;
+                    unsafeAtomicAdd(px + 0, n.x); unsafeAtomicAdd(px + 1, n.y); unsafeAtomicAdd(px + 2, n.z); unsafeAtomicAdd(px + 3, 1.0f);
+                }
+                if (!FLX_BXDF_IS_SINGULAR(mat.type) && !st.firstDiffuse[gid]) {
+                    st.firstDiffuse[gid] = 1u;
+                    const f3 albedo = mat_float3(sc, V(mat.Kd), hitUV, mat.map_Kd);              // not gamma-corrected
+                    float *px = fr.aovAlbedo + (size_t)pixIdx * 4;
+                    unsafeAtomicAdd(px + 0, albedo.x); unsafeAtomicAdd(px + 1, albedo.y); unsafeAtomicAdd(px + 2, albedo.z); unsafeAtomicAdd(px + 3, 1.0f);
+                }
+            }
             wr4(st.rec[S_HITN] + gid, mk4u(hitN, (hflags & 1u) | (backface ? 2u : 0u)));   // :212-213
 
             if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {    // next event estimation, :217-302

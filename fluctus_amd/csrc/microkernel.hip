@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256) void k_mk_reset(State st, Frame fr, flx_render
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= mk_limit(st, p)) return;
     reinterpret_cast<float4 *>(fr.pixels)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (fr.aovNormal) {                                                                           // src/mk_reset.cl:24-25
+        reinterpret_cast<float4 *>(fr.aovNormal)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        reinterpret_cast<float4 *>(fr.aovAlbedo)[gid] = make_float4(0.1f, 0.1f, 0.1f, 0.0f);
+    }
     st.phase[gid] = MK_GENERATE_CAMERA_RAY;
     float4 ei = rd4(st.rec[S_EI] + gid); wr4(st.rec[S_EI] + gid, make_float4(0.0f, 0.0f, 0.0f, ei.w));
     wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), gid));                                           // T = 1, seed = gid
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256) void k_mk_raygen(State st, flx_render_params p
     st.phase[gid] = MK_RT_NEXT_VERTEX;
 }
 
-__global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc, flx_render_params p, uint32_t *spill, uint32_t totalThreads, uint32_t *stats)
+__global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc, Frame fr, flx_render_params p, uint32_t *spill, uint32_t totalThreads, uint32_t *stats)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * MK_BLOCK];
     const uint32_t gid = blockIdx.x * MK_BLOCK + threadIdx.x;
@@ -102,6 +106,11 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
         primary = len == 0u;
         len += 1u;
         wr4(st.rec[S_DIR] + gid, mk4u(dir, len));
+        if (fr.aovNormal && len == 1u) {                             // first-hit normal, camera space (src/mk_next_vertex.cl:59-69); thread = pixel
+            float4 *px = reinterpret_cast<float4 *>(fr.aovNormal) + gid;
+            const float4 acc = *px; const f3 n = camera_space_normal(p, N);
+            *px = make_float4(acc.x + n.x, acc.y + n.y, acc.z + n.z, acc.w + 1.0f);
+        }
         uint32_t phase = MK_SAMPLE_BSDF;
         if (tri < 0) {                                               // miss: environment (src/mk_next_vertex.cl:72-93)
             f3 bg = mk3(0.0f);
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
     wave_count(&stats[1], active && !primary);
 }
 
-__global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc, flx_render_params p, uint32_t *spill, uint32_t totalThreads, uint32_t *stats)
+__global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc, Frame fr, flx_render_params p, uint32_t *spill, uint32_t totalThreads, uint32_t *stats)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * MK_BLOCK];
     const uint32_t gid = blockIdx.x * MK_BLOCK + threadIdx.x;
@@ -158,6 +167,12 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc,
         const bool backface = dot(h.N, rayDir) > 0.0f;
         if (backface) h.N = h.N * -1.0f;
         f3 orig = h.P - 1e-3f * rayDir;
+        if (fr.aovAlbedo && !FLX_BXDF_IS_SINGULAR(m.type) && !st.firstDiffuse[gid]) {            // src/mk_sample_bsdf.cl:56-66
+            st.firstDiffuse[gid] = 1u;
+            float4 *px = reinterpret_cast<float4 *>(fr.aovAlbedo) + gid;
+            const float4 acc = *px; const f3 al = mat_float3(sc, V(gm.Kd), h.uv, gm.map_Kd);
+            *px = make_float4(acc.x + al.x, acc.y + al.y, acc.z + al.z, acc.w + 1.0f);
+        }
         f3 Ei = ld3(rd4(st.rec[S_EI] + gid));
         const float eiw = rd4(st.rec[S_EI] + gid).w;
         const f3 T = ld3(thr);
@@ -263,15 +278,15 @@ void launch_mk_reset(hipStream_t s, const State &st, const Frame &fr, const flx_
 { hipLaunchKernelGGL(k_mk_reset, dim3((mkThreads(st, p) + 255) / 256), dim3(256), 0, s, st, fr, p); }
 void launch_mk_raygen(hipStream_t s, const State &st, const flx_render_params &p)
 { hipLaunchKernelGGL(k_mk_raygen, dim3((mkThreads(st, p) + 255) / 256), dim3(256), 0, s, st, p); }
-void launch_mk_next_vertex(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t *stats)
+void launch_mk_next_vertex(hipStream_t s, const State &st, const Scene &sc, const Frame &fr, const flx_render_params &p, uint32_t *spill, uint32_t *stats)
 {
     uint32_t blocks = (mkThreads(st, p) + MK_BLOCK - 1) / MK_BLOCK;
-    hipLaunchKernelGGL(k_mk_next_vertex, dim3(blocks), dim3(MK_BLOCK), 0, s, st, sc, p, spill, blocks * MK_BLOCK, stats);
+    hipLaunchKernelGGL(k_mk_next_vertex, dim3(blocks), dim3(MK_BLOCK), 0, s, st, sc, fr, p, spill, blocks * MK_BLOCK, stats);
 }
-void launch_mk_sample_bsdf(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t *stats)
+void launch_mk_sample_bsdf(hipStream_t s, const State &st, const Scene &sc, const Frame &fr, const flx_render_params &p, uint32_t *spill, uint32_t *stats)
 {
     uint32_t blocks = (mkThreads(st, p) + MK_BLOCK - 1) / MK_BLOCK;
-    hipLaunchKernelGGL(k_mk_sample_bsdf, dim3(blocks), dim3(MK_BLOCK), 0, s, st, sc, p, spill, blocks * MK_BLOCK, stats);
+    hipLaunchKernelGGL(k_mk_sample_bsdf, dim3(blocks), dim3(MK_BLOCK), 0, s, st, sc, fr, p, spill, blocks * MK_BLOCK, stats);
 }
 void launch_mk_splat(hipStream_t s, const State &st, const Frame &fr, const flx_render_params &p, uint32_t *stats, int preview)
 { hipLaunchKernelGGL(k_mk_splat, dim3((mkThreads(st, p) + 255) / 256), dim3(256), 0, s, st, fr, p, stats, preview); }

@@ -29,7 +29,13 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame
 {
     const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
     if (gid >= n) return;
-    if (gid < fr.localPixels) reinterpret_cast<float4 *>(fr.pixels)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (gid < fr.localPixels) {
+        reinterpret_cast<float4 *>(fr.pixels)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (fr.aovNormal) {                                                                      // src/wf_reset.cl:22-24
+            reinterpret_cast<float4 *>(fr.aovNormal)[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            reinterpret_cast<float4 *>(fr.aovAlbedo)[gid] = make_float4(0.1f, 0.1f, 0.1f, 0.0f);   // default for direct emission
+        }
+    }
     if (gid >= st.numTasks) return;
     init_path_state(st, gid, 2.0f * p.worldRadius);
     wr4(st.rec[S_EI] + gid, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)));     // Ei, pixelIndex
@@ -116,6 +122,11 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_postprocess(Frame fr, flx_render
     if (p.tmOperator == 2u) col = uc2_func(2.0f * col) / uc2_func(mk3(11.2f));
     col = pow3(col, 1.0f / 2.2f);
     reinterpret_cast<float4 *>(fr.preview)[gid] = mk4(col, w);
+    if (fr.aovNormal) {                                                                          // src/mk_postprocess.cl:49-54
+        const float4 n = reinterpret_cast<const float4 *>(fr.aovNormal)[gid], a = reinterpret_cast<const float4 *>(fr.aovAlbedo)[gid];
+        reinterpret_cast<float4 *>(fr.aovNormalOut)[gid] = n.w > 1.0f ? make_float4(n.x / n.w, n.y / n.w, n.z / n.w, n.w / n.w) : n;
+        reinterpret_cast<float4 *>(fr.aovAlbedoOut)[gid] = a.w > 1.0f ? make_float4(a.x / a.w, a.y / a.w, a.z / a.w, a.w / a.w) : a;
+    }
 }
 
 // ---- test hooks: internal packed layout <-> reference 64-column SoA (src/geom.h:199-236)

@@ -43,6 +43,7 @@ public:
     void enqueueSplatKernel(const RenderParams &params);
     void enqueueSplatPreviewKernel(const RenderParams &params);
     void fetchStatsAsync();                                       // src/clcontext.cpp:642-646; folded into statsAsync by finishQueue()
+    void recompileKernels(bool useDenoiser);                      // src/clcontext.cpp:852-874: here only the denoiser-feature switch
     void enqueueClearWfQueues();                                  // src/clcontext.cpp:877-883
     void enqueueGetCounters(QueueCounters *cnt);                  // async; valid after finishQueue()
     void enqueuePostprocessKernel(const RenderParams &params);

@@ -138,7 +138,8 @@ int fh_tracer_params(void *t, void *out240, const void *in240)
     FH_CATCH
 }
 int fh_tracer_update(void *t, void *counters32) { FH_TRY ((Tracer *)t)->update(); if (counters32) memcpy(counters32, &((Tracer *)t)->lastCounters(), 32); FH_CATCH }
-int fh_tracer_render_single(void *t, int spp) { FH_TRY ((Tracer *)t)->renderSingle(spp); FH_CATCH }
+int fh_tracer_render_single(void *t, int spp, int denoise) { FH_TRY ((Tracer *)t)->renderSingle(spp, denoise != 0); FH_CATCH }
+int fh_tracer_set_denoiser(void *t, int on) { FH_TRY ((Tracer *)t)->setDenoiser(on != 0); FH_CATCH }
 int fh_tracer_toggle_renderer(void *t) { FH_TRY ((Tracer *)t)->toggleRenderer(); FH_CATCH }
 int fh_tracer_uses_wavefront(void *t) { return ((Tracer *)t)->usesWavefront() ? 1 : 0; }
 int fh_tracer_stats(void *t, uint64_t *out4)

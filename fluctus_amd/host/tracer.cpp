@@ -105,12 +105,13 @@ void Tracer::setEnvMap(const std::string &hdrFile)
 }
 
 // reference: src/tracer.cpp:95-187
-void Tracer::renderSingle(int spp)
+void Tracer::renderSingle(int spp, bool denoise)
 {
     if (useWavefront) toggleRenderer();                                  // only MK guarantees the spp of every pixel (:99-101)
     if ((uint64_t)params.width * params.height > clctx->getNumTasks())
         throw std::runtime_error("renderSingle: width*height exceeds the context's numTasks (one path per pixel)");
     params.useRoulette = 0;                                              // :104-108
+    if (denoise) setDenoiser(true);                                      // :110-114
     clctx->updateParams(params); paramsUpdatePending = false;
     clctx->enqueueResetKernel(params);
     for (int sample = 0; sample < spp; sample++) {

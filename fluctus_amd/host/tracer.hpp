@@ -25,7 +25,8 @@ public:
     std::string runBenchmark(double seconds, int iterations = 0);
     // final-frame render: exactly `spp` samples in every pixel (reference: src/tracer.cpp:95-187).  Switches to the
     // microkernel integrator and turns Russian roulette off, as the reference does; needs numTasks >= width*height.
-    void renderSingle(int spp);
+    void renderSingle(int spp, bool denoise = false);                             // denoise: also fill the denoiser feature buffers
+    void setDenoiser(bool on) { useDenoiser = on; clctx->recompileKernels(on); iteration = 0; }
     void toggleRenderer() { useWavefront = !useWavefront; iteration = 0; }        // src/tracer.cpp:881-886
     bool usesWavefront() const { return useWavefront; }
     void saveImage(const std::string &filename) { clctx->saveImage(filename, params); }
@@ -53,6 +54,7 @@ private:
     BVH *bvh = nullptr;
     uint32_t iteration = 0;
     bool paramsUpdatePending = true;
+    bool useDenoiser = false;                                                     // feature buffers only; the OptiX denoiser itself is out of scope
     bool useWavefront = true;                                                     // this library's default; the reference starts on MK (src/tracer.cpp:11)
     QueueCounters lastCnt {};
     std::string sceneName;

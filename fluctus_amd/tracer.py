@@ -44,9 +44,13 @@ class Tracer:
         host._chk(self.L.fh_tracer_update(self.h, cnt.ctypes.data_as(C.c_void_p)))
         return cnt
 
-    def render_single(self, spp):
-        """Tracer::renderSingle (src/tracer.cpp:95-187): exactly spp samples per pixel on the microkernel integrator."""
-        host._chk(self.L.fh_tracer_render_single(self.h, int(spp)))
+    def render_single(self, spp, denoise=False):
+        """Tracer::renderSingle (src/tracer.cpp:95-187): exactly spp samples per pixel on the microkernel integrator;
+        denoise=True also fills the denoiser feature buffers (read_pixels(2) albedo, read_pixels(3) normals)."""
+        host._chk(self.L.fh_tracer_render_single(self.h, int(spp), int(bool(denoise))))
+
+    def set_denoiser(self, on):
+        host._chk(self.L.fh_tracer_set_denoiser(self.h, int(bool(on))))
 
     def toggle_renderer(self):
         host._chk(self.L.fh_tracer_toggle_renderer(self.h))

@@ -87,7 +87,12 @@ uint32_t flx_num_tasks(flx_ctx *ctx);
  * the preview buffer is a plain device buffer, no GL interop. */
 int flx_postprocess(flx_ctx *ctx);
 /* saveImage's read-back half (src/clcontext.cpp:386-465): which = 0 raw accumulation (rgb sum,
- * sample count), 1 = post-processed preview.  Blocking; out = float4 per (local) pixel. */
+ * sample count), 1 = post-processed preview.  Blocking; out = float4 per (local) pixel.
+ * With flx_set_option(ctx, "denoiser", 1) -- the reference's USE_OPTIX_DENOISER kernel build (recompileKernels,
+ * src/clcontext.cpp:852-874; buffers :337-338) -- `logic` / the microkernels also accumulate the denoiser feature
+ * buffers and flx_postprocess resolves them: which = 2 albedo of the first non-singular hit, 3 first-hit normal in
+ * camera space (both as written to denoiserAlbedoGL / denoiserNormalGL, src/mk_postprocess.cl:49-54), 4 / 5 the raw
+ * accumulators (sum, count). */
 int flx_read_pixels(flx_ctx *ctx, int which, float *out_rgba);
 
 /* ---- microkernel integrator (the reference's second integrator).  One path per pixel (needs
@@ -151,6 +156,7 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     2 (default) as 1, and it starts as soon as `logic` is done when only raygen / materials / extend
  *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip)
  *   node_layout       1 (default) sibling-pair record numbering | 0 DFS numbering; takes effect at the next flx_upload_scene
+ *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
  *   compact_nodes, xcd_remap, refill_thresh, stream_refill, stream_inner_min, stream_waves_ext, stream_waves_shadow */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
 
