@@ -89,6 +89,20 @@ def load_png(path):
     return out
 
 
+load_texture = load_png      # PNG or JPEG, decided by the file signature
+
+
+def decode_jpeg(data):
+    """JPEG bytes -> (h, w, 3) uint8, top-left origin: the bytes libjpeg's default decode path produces."""
+    L = lib()
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    _chk(L.fh_jpeg_decode(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(w), C.byref(h), None, C.c_uint64(0)))
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    _chk(L.fh_jpeg_decode(buf.ctypes.data_as(C.c_void_p), C.c_uint64(buf.size), C.byref(w), C.byref(h), out.ctypes.data_as(C.c_void_p), C.c_uint64(out.size)))
+    return out
+
+
 BVH_MODES = {"sbvh": 0, "sah": 1, "binned": 2}
 
 

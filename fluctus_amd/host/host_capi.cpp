@@ -56,12 +56,23 @@ int fh_scene_set_tri_material(void *s, uint64_t first, uint64_t count, int matId
     FH_CATCH
 }
 
+// PNG or JPEG by file signature (the name is historical); RGBA8, lower-left origin
 int fh_png_load(const char *path, uint32_t *w, uint32_t *h, uint8_t *rgba /* null: query size */)
 {
     FH_TRY
-    Texture t = loadPNG(path);
+    Texture t = loadTexture(path);
     *w = t.width; *h = t.height;
     if (rgba) memcpy(rgba, t.rgba.data(), t.rgba.size());
+    FH_CATCH
+}
+
+// JPEG from memory: RGB8, top-left origin (libjpeg scanline order); rgb == null queries the size
+int fh_jpeg_decode(const uint8_t *data, uint64_t size, uint32_t *w, uint32_t *h, uint8_t *rgb, uint64_t cap)
+{
+    FH_TRY
+    std::vector<uint8_t> out;
+    decodeJPEG(data, (size_t)size, w, h, out);
+    if (rgb) { if (out.size() > cap) throw std::runtime_error("fh_jpeg_decode: buffer too small"); memcpy(rgb, out.data(), out.size()); }
     FH_CATCH
 }
 

@@ -186,14 +186,14 @@ void Scene::loadObjWithMaterials(const std::string &filePath)
     int curMat = -1;
     std::string line;
     // Scene::tryImportTexture (reference: src/scene.cpp:303-330): reuse a texture already loaded under this name,
-    // else decode the file (PNG only here; anything else, or a decode failure, leaves the slot at -1 like a missing file)
+    // else decode the file (PNG or JPEG, by signature; anything else, or a decode failure, leaves the slot at -1 like a missing file)
     auto texLookup = [&](const std::string &nm) -> int {
         if (nm.empty()) return -1;
         std::string unix = nm; for (char &ch : unix) if (ch == '\\') ch = '/';
         for (size_t i = 0; i < textures.size(); i++) if (textures[i].name == unix) return (int)i;
         const std::string full = folder + unix;
-        if (unix.size() > 4 && (unix.compare(unix.size() - 4, 4, ".png") == 0 || unix.compare(unix.size() - 4, 4, ".PNG") == 0) && fileExists(full)) {
-            try { Texture t = loadPNG(full); t.name = unix; return addTexture(std::move(t)); } catch (const std::exception &) { return -1; }
+        if (fileExists(full)) {
+            try { Texture t = loadTexture(full); t.name = unix; return addTexture(std::move(t)); } catch (const std::exception &) { return -1; }
         }
         return -1;
     };

@@ -235,3 +235,79 @@ def test_obj_loader_resolves_png_textures():
     from PIL import Image
     ref = np.asarray(Image.open(REF + "/egyptcat/EgyptCat.png").convert("RGBA"))[::-1]
     assert np.array_equal(d.texdata.reshape(1024, 1024, 4), ref)
+
+
+def _jpeg_image(w, h, mode, seed):
+    """Smooth gradients + texture + hard edges + noise: exercises DC prediction, long zero runs, EOB runs and ringing."""
+    rng = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    r = 127 + 120 * np.sin(x / 9.0) * np.cos(y / 13.0)
+    g = 255.0 * x / max(1, w - 1)
+    b = 255.0 * ((x // 8 + y // 8) % 2)
+    img = np.stack([r, g, b], -1) + rng.normal(0, 6, (h, w, 3))
+    img[h // 3: h // 3 + 5, :, :] = 255
+    arr = img.clip(0, 255).astype(np.uint8)
+    return arr[..., 1] if mode == "L" else arr
+
+
+@pytest.mark.parametrize("size", [(64, 48), (37, 23), (17, 9), (8, 8), (1, 1), (3, 130)])
+@pytest.mark.parametrize("kw", [dict(quality=90, subsampling=0), dict(quality=75, subsampling=1), dict(quality=60, subsampling=2),
+                                dict(quality=95, subsampling=2, progressive=True), dict(quality=50, subsampling=0, progressive=True, optimize=True),
+                                dict(quality=85, subsampling=2, optimize=True, restart_marker_blocks=3), dict(quality=30, subsampling=1, restart_marker_rows=1),
+                                dict(quality=100, subsampling=0), dict(quality=5, subsampling=2)],
+                         ids=["444", "422", "420", "420-progressive", "444-progressive-opt", "420-restart-blocks", "422-restart-rows", "q100", "q5"])
+def test_jpeg_decoder_is_bit_identical_to_libjpeg(size, kw):
+    """SURVEY 8(f) N2.  host/jpeg.cpp restates libjpeg's default decode path (ISLOW IDCT, fancy upsampling, fixed-point
+    YCbCr->RGB); Pillow decodes with libjpeg-turbo, whose output is defined to equal libjpeg's: every byte must match."""
+    from PIL import Image
+    import io
+    w, h = size
+    for mode in ("RGB", "L"):
+        arr = _jpeg_image(w, h, mode, seed=w * 131 + h)
+        buf = io.BytesIO()
+        Image.fromarray(arr, mode).save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        expect = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        got = host.decode_jpeg(data)
+        assert got.shape == expect.shape
+        assert np.array_equal(got, expect), f"{mode} {kw}: {(got != expect).mean():.4%} of the bytes differ"
+
+
+def test_jpeg_loader_origin_and_errors(tmp_path):
+    from PIL import Image
+    arr = _jpeg_image(40, 24, "RGB", 3)
+    path = str(tmp_path / "t.jpg")
+    Image.fromarray(arr, "RGB").save(path, "JPEG", quality=92)
+    ref = np.asarray(Image.open(path).convert("RGBA"))
+    got = host.load_texture(path)                                   # dispatch on the file signature, lower-left origin, alpha 255
+    assert got.shape == (24, 40, 4) and np.array_equal(got, ref[::-1])
+    for bad in (b"\xff\xd8\xff\xd9", b"\xff\xd8" + b"\x00" * 40, b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x08\x00\x08\x01\x01\x11\x00"):   # no frame; garbage; arithmetic coding
+        with pytest.raises(RuntimeError):
+            host.decode_jpeg(bad)
+    data = open(path, "rb").read()
+    trunc = host.decode_jpeg(data[: len(data) * 2 // 3])           # truncated entropy data: zero-filled like libjpeg, no crash
+    assert trunc.shape == (24, 40, 3)
+
+
+@needs_ref_assets
+def test_jpeg_decoder_on_the_country_kitchen_textures():
+    """The reference's own JPEG assets (baseline 4:4:4, baseline 4:2:0, progressive; Exif / JFIF / Adobe headers)."""
+    from PIL import Image
+    import glob
+    files = sorted(glob.glob(REF + "/country_kitchen/textures/*.jpg"))
+    assert len(files) >= 10
+    for f in files:
+        expect = np.asarray(Image.open(f).convert("RGB"))
+        assert np.array_equal(host.decode_jpeg(open(f, "rb").read()), expect), f
+
+
+def test_obj_loader_resolves_jpeg_textures(tmp_path):
+    from PIL import Image
+    arr = _jpeg_image(32, 16, "RGB", 9)
+    Image.fromarray(arr, "RGB").save(str(tmp_path / "wood.jpg"), "JPEG", quality=80, subsampling=2)
+    (tmp_path / "m.mtl").write_text("newmtl wood\nKd 0.5 0.5 0.5\nmap_Kd wood.jpg\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl wood\nf 1/1 2/2 3/3\n")
+    d = host.load_scene(str(tmp_path / "m.obj"))
+    assert d.texdesc.size == 1 and tuple(d.texdesc[0])[1:] == (32, 16) and d.materials[1]["map_Kd"] == 0
+    ref = np.asarray(Image.open(str(tmp_path / "wood.jpg")).convert("RGBA"))[::-1]
+    assert np.array_equal(d.texdata.reshape(16, 32, 4), ref)
