@@ -87,14 +87,18 @@ def usable_cores():
 
 
 def cpu_baseline(d, p, env, budget_s=12.0):
-    """The oracle (CPU restatement of the reference kernels) on the host cores, bounded sample: the same
-    scene / camera / parameters with 65 536 paths in flight, 16 warm-up iterations, then whole iterations
-    until `budget_s` seconds have elapsed."""
+    """CPU baseline on the host cores, bounded sample: the same scene / camera / parameters with 65 536 paths in flight,
+    16 warm-up iterations, then whole iterations until `budget_s` seconds have elapsed.
+
+    kind "reference": oracle/_ref/libfluctus_ref.so -- the reference's OWN OpenCL kernels compiled for x86-64 in the build
+    container (oracle/ref/Makefile), their NDRanges spread over the usable cores in chunks of 64 work-items the way a CPU
+    OpenCL device schedules work-groups.  kind "port" (fallback when that library is absent): oracle/wf_oracle.cpp."""
     from fluctus_amd import driver
-    from oracle.binding import OracleContext
+    from oracle.binding import OracleContext, RefContext, ref_available
     cores = usable_cores()
     n = 1 << 16
-    c = OracleContext(n, threads=cores)
+    kind = "reference" if ref_available() and os.environ.get("FLX_CPU_BASELINE", "") != "port" else "port"
+    c = RefContext(n, threads=cores) if kind == "reference" else OracleContext(n, threads=cores)
     c.upload_scene(d)
     c.upload_envmap(env)
     c.set_params(p)
@@ -110,8 +114,9 @@ def cpu_baseline(d, p, env, budget_s=12.0):
         iters += 1
     dt = time.perf_counter() - t0
     c.close()
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"same scene/params, 65536 paths in flight, {iters} iterations after 16 warm-up, {dt:.1f} s"}
+    what = "the reference's wf_*.cl kernels built for x86-64 (oracle/_ref), NDRange over host threads" if kind == "reference" else "oracle/wf_oracle.cpp (OpenMP)"
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": f"{what}; same scene/params, 65536 paths in flight, {iters} iterations after 16 warm-up, {dt:.1f} s"}
 
 
 def main():

@@ -66,8 +66,7 @@ class OracleContext:
         self.h = C.c_void_p()
         self.num_tasks = int(num_tasks)
         assert self.L.orc_create(C.c_uint32(num_tasks), C.byref(self.h)) == 0
-        if not _ref:
-            self.L.orc_set_threads(self.h, int(threads))
+        self.L.orc_set_threads(self.h, int(threads))
         self.params = None
 
     def close(self):
@@ -169,5 +168,5 @@ class RefContext(OracleContext):
     """Same interface, backed by the reference's own kernels (oracle/_ref)."""
     name = "reference"
 
-    def __init__(self, num_tasks):
-        super().__init__(num_tasks, _ref=True)
+    def __init__(self, num_tasks, threads=1):
+        super().__init__(num_tasks, threads=threads, _ref=True)

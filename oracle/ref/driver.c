@@ -14,7 +14,7 @@
 #include <stdio.h>
 #include "../../include/fluctus_wire.h"
 
-extern size_t ref_current_gid;
+extern __thread size_t ref_current_gid;
 typedef struct { int width, height; const float *rgba; } ref_image;
 typedef unsigned int uint;
 
@@ -79,6 +79,7 @@ typedef struct {
     flx_render_params params __attribute__((aligned(64)));   /* kernels load float3 members with aligned 16-byte moves */
     float *pixels, *preview, *denAlbedo, *denNormal, *denAlbedoGL, *denNormalGL;
     int denoiser;
+    int threads;
     size_t npix;
     void *tris; size_t ntris; uint *indices; size_t nidx; void *nodes; size_t nnodes;
     void *materials; size_t nmat; void *texdesc; size_t ntex; uint8_t *texdata; size_t texbytes;
@@ -144,7 +145,15 @@ int ref_set_params(ref_ctx *c, const void *p240)
     return 0;
 }
 
-#define RANGE(n, call) for (size_t g_ = 0; g_ < (size_t)(n); g_++) { ref_current_gid = g_; call; }
+/* NDRange: ascending ids on one thread (default; deterministic queue order for the parity tests) or chunks of 64
+ * work-items over c->threads host threads, as a CPU OpenCL device would schedule work-groups */
+#define RANGE(n, call) do { \
+    const long n_ = (long)(n); \
+    if (c->threads > 1) { \
+        _Pragma("omp parallel for schedule(dynamic, 64) num_threads(c->threads)") \
+        for (long g_ = 0; g_ < n_; g_++) { ref_current_gid = (size_t)g_; call; } \
+    } else for (long g_ = 0; g_ < n_; g_++) { ref_current_gid = (size_t)g_; call; } \
+} while (0)
 
 int ref_wf_reset(ref_ctx *c)
 {
@@ -210,6 +219,7 @@ int ref_read_pixels(ref_ctx *c, int which, float *out)
     memcpy(out, src[which], c->npix * 16);
     return 0;
 }
+int ref_set_threads(ref_ctx *c, int n) { c->threads = n < 1 ? 1 : n; return 0; }
 int ref_set_option(ref_ctx *c, const char *name, int value) { if (name && strcmp(name, "denoiser") == 0) { c->denoiser = value != 0; return 0; } return 1; }
 int ref_state_export(ref_ctx *c, float *out) { memcpy(out, c->tasks, (size_t)FLX_NUM_COLS * c->numTasks * 4); return 0; }
 int ref_state_import(ref_ctx *c, const float *in) { memcpy(c->tasks, in, (size_t)FLX_NUM_COLS * c->numTasks * 4); return 0; }

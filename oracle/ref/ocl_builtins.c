@@ -9,8 +9,9 @@
  * s6.12.11 atomics, s6.12.14 image read), which an OpenCL CPU runtime would normally supply.
  * Math built-ins forward to the C library's float functions (sinf, cosf, ...); native_* forward
  * to the same (the reference uses native_* only as a speed hint).  No FMA contraction.
- * Work-items run sequentially in ascending global id, so atomics are plain read-modify-writes
- * and barrier() is a no-op.  Symbols carry the Itanium-mangled names clang emits for the
+ * Work-items run in ascending global id on one thread (the parity tests: deterministic queue order) or,
+ * with ref_set_threads(n > 1), spread over n host threads like a CPU OpenCL device (bench.py's cpu_baseline):
+ * the current id is thread-local and the atomics are real; barrier() is a no-op (no kernel on the path needs one).  Symbols carry the Itanium-mangled names clang emits for the
  * overloadable built-ins (checked with `nm`).
  */
 #include <math.h>
@@ -24,7 +25,7 @@ typedef float float4 __attribute__((ext_vector_type(4)));
 typedef int int2 __attribute__((ext_vector_type(2)));
 
 /* ---- work-item functions (s6.12.1) */
-size_t ref_current_gid = 0;
+__thread size_t ref_current_gid = 0;
 size_t b_get_global_id(unsigned d) __asm__("_Z13get_global_idj");
 size_t b_get_global_id(unsigned d) { return d == 0 ? ref_current_gid : 0; }
 size_t b_get_local_id(unsigned d) __asm__("_Z12get_local_idj");
@@ -32,17 +33,27 @@ size_t b_get_local_id(unsigned d) { return d == 0 ? (ref_current_gid & 63) : 0; 
 void b_barrier(unsigned f) __asm__("_Z7barrierj");
 void b_barrier(unsigned f) { (void)f; }
 
-/* ---- atomics (s6.12.11), sequential execution */
+/* ---- atomics (s6.12.11) */
 unsigned b_atomic_inc_g(volatile unsigned *p) __asm__("_Z10atomic_incPU8CLglobalVj");
-unsigned b_atomic_inc_g(volatile unsigned *p) { unsigned o = *p; *p = o + 1; return o; }
+unsigned b_atomic_inc_g(volatile unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 unsigned b_atomic_inc_l(volatile unsigned *p) __asm__("_Z10atomic_incPU7CLlocalVj");
-unsigned b_atomic_inc_l(volatile unsigned *p) { unsigned o = *p; *p = o + 1; return o; }
+unsigned b_atomic_inc_l(volatile unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
 unsigned b_atomic_add_g(volatile unsigned *p, unsigned v) __asm__("_Z10atomic_addPU8CLglobalVjj");
-unsigned b_atomic_add_g(volatile unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+unsigned b_atomic_add_g(volatile unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 float b_atomic_xchg_f(volatile float *p, float v) __asm__("_Z11atomic_xchgPU8CLglobalVff");
-float b_atomic_xchg_f(volatile float *p, float v) { float o = *p; *p = v; return o; }
+float b_atomic_xchg_f(volatile float *p, float v)
+{
+    unsigned in, out; __builtin_memcpy(&in, &v, 4);
+    out = __atomic_exchange_n((volatile unsigned *)p, in, __ATOMIC_RELAXED);
+    float o; __builtin_memcpy(&o, &out, 4); return o;
+}
 unsigned b_atomic_cmpxchg(volatile unsigned *p, unsigned c, unsigned v) __asm__("_Z14atomic_cmpxchgPU8CLglobalVjjj");
-unsigned b_atomic_cmpxchg(volatile unsigned *p, unsigned c, unsigned v) { unsigned o = *p; if (o == c) *p = v; return o; }
+unsigned b_atomic_cmpxchg(volatile unsigned *p, unsigned c, unsigned v)
+{
+    unsigned expected = c;
+    __atomic_compare_exchange_n(p, &expected, v, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return expected;                                   /* the old value, whether or not the swap happened */
+}
 
 /* ---- math (s6.12.2) */
 float b_sin(float x) __asm__("_Z3sinf");   float b_sin(float x) { return sinf(x); }

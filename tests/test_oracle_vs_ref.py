@@ -270,3 +270,28 @@ def test_denoiser_features_microkernel():
         c.postprocess()
     for which in (2, 3):
         assert np.allclose(a.read_pixels(which), b.read_pixels(which), rtol=1e-4, atol=1e-5)
+
+
+def test_reference_kernels_on_host_threads_agree_statistically():
+    """bench.py's cpu_baseline (kind "reference") spreads the NDRanges of the reference kernels over host threads, like a CPU
+    OpenCL device: queue ORDER then depends on timing (as it does on the reference's real devices), the estimate must not."""
+    from oracle.binding import RefContext
+    d = common.mixed_material_scene()
+    w, h, n = 64, 48, 4096
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)
+    outs = []
+    for threads in (1, 4):
+        c = RefContext(n, threads=threads)
+        c.upload_scene(d); c.upload_envmap(host.synthetic_sky(64, 32)); c.set_params(p)
+        driver.reset_renderer(c)
+        tot = np.zeros(8, np.int64)
+        for _ in range(60):
+            cnt = driver.benchmark_iteration(c, w * h)
+            assert int(cnt[Q.RAYGEN]) + int(cnt[3:8].sum()) == n and int(cnt[Q.EXTENSION]) == n      # invariants hold under real atomics
+            tot += cnt
+        px = c.read_pixels(0)
+        assert np.isfinite(px).all()
+        outs.append((tot, px[:, :3].sum() / max(1.0, px[:, 3].sum())))
+    (t1, m1), (t4, m4) = outs
+    assert abs(int(t1[Q.RAYGEN]) - int(t4[Q.RAYGEN])) <= 0.03 * t1[Q.RAYGEN] and abs(int(t1[Q.SHADOW]) - int(t4[Q.SHADOW])) <= 0.03 * t1[Q.SHADOW]
+    assert abs(m1 - m4) <= 0.05 * m1
