@@ -40,6 +40,7 @@ class SceneData:
         self.nodes = self.indices = None
         self.world_radius = 1.0
         self.type_bits = 0
+        self.world_up = (0.0, 1.0, 0.0)
         self.bvh_metrics = None
 
 
@@ -54,6 +55,9 @@ def _scene_to_data(h):
     d.texdata = np.zeros(tb.value, np.uint8)
     _chk(L.fh_scene_get(h, _p(d.tris), _p(d.materials), _p(d.texdesc), _p(d.texdata)))
     d.type_bits = bits.value
+    up = np.zeros(3, np.float32)
+    L.fh_scene_world_up(h, up.ctypes.data_as(C.c_void_p))
+    d.world_up = tuple(float(x) for x in up)
     return d
 
 

@@ -25,6 +25,7 @@ const char *fh_last_error() { return g_err.c_str(); }
 int fh_scene_create(void **out) { FH_TRY *out = new Scene(); FH_CATCH }
 int fh_scene_destroy(void *s) { delete (Scene *)s; return 0; }
 int fh_scene_load(void *s, const char *path) { FH_TRY ((Scene *)s)->loadModel(path); FH_CATCH }
+int fh_scene_world_up(void *s, float *out3) { flx_vec3 u = ((Scene *)s)->getWorldUp(); out3[0] = u.x; out3[1] = u.y; out3[2] = u.z; return 0; }
 int fh_scene_generate(void *s, const char *kind, uint32_t targetTris, uint32_t seed) { FH_TRY ((Scene *)s)->generate(kind, targetTris, seed); FH_CATCH }
 int fh_scene_counts(void *s, uint64_t *ntris, uint64_t *nmats, uint64_t *ntex, uint64_t *texbytes, uint32_t *typeBits)
 {

@@ -58,6 +58,13 @@ Scene::Scene()
     addMaterial(defaultMaterial());   // reference: scene.cpp:13-26
 }
 
+int Scene::tryImportTexture(const std::string &path, const std::string &name)
+{
+    for (size_t i = 0; i < textures.size(); i++) if (textures[i].name == name) return (int)i;
+    if (!fileExists(path)) return -1;
+    try { Texture t = loadTexture(path); t.name = name; return addTexture(std::move(t)); } catch (const std::exception &) { return -1; }
+}
+
 int Scene::parseShaderType(const std::string &type)
 {
     if (type == "diffuse") return FLX_BXDF_DIFFUSE;
@@ -74,6 +81,7 @@ void Scene::loadModel(const std::string &filename)
 {
     if (endsWith(filename, "obj")) loadObjWithMaterials(filename);
     else if (endsWith(filename, "ply")) loadPlyModel(filename);
+    else if (endsWith(filename, "pbrt")) loadPBRTModel(filename);
     else throw std::runtime_error("Scene::loadModel: unsupported format: " + filename);
 }
 
@@ -185,17 +193,10 @@ void Scene::loadObjWithMaterials(const std::string &filePath)
     int matBase = (int)materials.size();   // == 1 for a fresh scene
     int curMat = -1;
     std::string line;
-    // Scene::tryImportTexture (reference: src/scene.cpp:303-330): reuse a texture already loaded under this name,
-    // else decode the file (PNG or JPEG, by signature; anything else, or a decode failure, leaves the slot at -1 like a missing file)
     auto texLookup = [&](const std::string &nm) -> int {
         if (nm.empty()) return -1;
         std::string unix = nm; for (char &ch : unix) if (ch == '\\') ch = '/';
-        for (size_t i = 0; i < textures.size(); i++) if (textures[i].name == unix) return (int)i;
-        const std::string full = folder + unix;
-        if (fileExists(full)) {
-            try { Texture t = loadTexture(full); t.name = unix; return addTexture(std::move(t)); } catch (const std::exception &) { return -1; }
-        }
-        return -1;
+        return tryImportTexture(folder + unix, unix);
     };
     while (std::getline(in, line)) {
         if (line.size() < 2) continue;

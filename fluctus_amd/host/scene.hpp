@@ -26,6 +26,7 @@ public:
     void loadModel(const std::string &filename);    // dispatch on extension (scene.cpp:53-103)
     void loadPlyModel(const std::string &filename);
     void loadObjWithMaterials(const std::string &filename);
+    void loadPBRTModel(const std::string &filename);   // pbrt-v3 text scenes (reference: .pbrt -> .pbf -> loadPBFModel, scene.cpp:74-90, 574-813); pbrt.cpp
 
     // Deterministic procedural stand-ins for the configs whose assets are missing from the
     // reference checkout; "kitchen" | "conference" | "courtyard".
@@ -36,6 +37,10 @@ public:
     std::vector<Texture> &getTextures() { return textures; }
     uint32_t getMaterialTypes() const { return materialTypes; }
     int addTexture(Texture &&t) { textures.push_back(std::move(t)); return (int)textures.size() - 1; }
+    // Scene::tryImportTexture (reference: src/scene.cpp:303-330): reuse a texture already loaded under `name`, else decode the
+    // file (PNG / JPEG); -1 when missing or undecodable
+    int tryImportTexture(const std::string &path, const std::string &name);
+    flx_vec3 getWorldUp() const { return worldUp; }
     int addMaterial(const flx_material &m) { materials.push_back(m); materialTypes |= (uint32_t)m.type; return (int)materials.size() - 1; }
 
     // packTextures (reference: src/clcontext.cpp:570-611): one byte blob + descriptors
@@ -48,6 +53,7 @@ private:
     std::vector<flx_material> materials;
     std::vector<Texture> textures;
     uint32_t materialTypes = 0;
+    flx_vec3 worldUp {0.0f, 1.0f, 0.0f, 0.0f};          // reference: Scene::worldUp, set by the PBRT path from the camera frame
 };
 
 } // namespace fluctus

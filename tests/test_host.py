@@ -311,3 +311,107 @@ def test_obj_loader_resolves_jpeg_textures(tmp_path):
     assert d.texdesc.size == 1 and tuple(d.texdesc[0])[1:] == (32, 16) and d.materials[1]["map_Kd"] == 0
     ref = np.asarray(Image.open(str(tmp_path / "wood.jpg")).convert("RGBA"))[::-1]
     assert np.array_equal(d.texdata.reshape(16, 32, 4), ref)
+
+
+# ---------------------------------------------------------------- PBRT ingest (parity unpinned, see host/pbrt.cpp)
+PBRT_SCENE = '''
+# a hand-built pbrt-v3 scene exercising the subset the reference's loader maps (src/scene.cpp:574-813)
+LookAt 0 -6 2   0 0 1   0 0 1          # Z-up camera
+Camera "perspective" "float fov" [ 45 ]
+Film "image" "integer xresolution" [ 64 ] "integer yresolution" [ 48 ] "string filename" "out.png"
+Sampler "halton" "integer pixelsamples" 4
+WorldBegin
+LightSource "infinite" "rgb L" [ 1 1 1 ]
+Texture "wood" "spectrum" "imagemap" "string filename" "wood.jpg"
+Texture "scaled" "float" "scale" "float tex1" 2 "float tex2" 3
+MakeNamedMaterial "gold" "string type" "metal" "rgb eta" [ 0.2 0.9 1.1 ] "rgb k" [ 3 2.3 1.8 ] "float roughness" 0.2
+MakeNamedMaterial "pane" "string type" "glass" "float index" 1.33 "rgb Kt" [ .9 .9 .9 ]
+AttributeBegin
+  Material "matte" "texture Kd" "wood"
+  Translate 1 2 3
+  Shape "trianglemesh" "integer indices" [ 0 1 2  0 2 3 ] "point P" [ 0 0 0  1 0 0  1 1 0  0 1 0 ] "float uv" [ 0 0  1 0  1 1  0 1 ]
+AttributeEnd
+AttributeBegin
+  NamedMaterial "gold"
+  Scale 2 2 2
+  Rotate 90 0 0 1
+  Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 1 0 0  0 1 0  0 0 1 ] "normal N" [ 0 0 1  0 0 1  0 0 1 ]
+  Shape "sphere" "float radius" 1        # skipped by the reference too
+AttributeEnd
+ObjectBegin "leaf"
+  Material "plastic" "rgb Kd" [ .1 .6 .1 ] "rgb Ks" [ .3 .3 .3 ] "float roughness" 0.05
+  Shape "plymesh" "string filename" "leaf.ply"
+ObjectEnd
+AttributeBegin
+  Translate 10 0 0
+  ObjectInstance "leaf"
+  Translate 0 5 0
+  ObjectInstance "leaf"
+AttributeEnd
+NamedMaterial "pane"
+Shape "trianglemesh" "point P" [ 0 0 5  1 0 5  0 1 5 ]
+Material "mirror"
+Include "more.pbrt"
+WorldEnd
+'''
+
+
+def _write_ply(path, binary):
+    verts = np.array([[0, 0, 0, 0, 0, 1, 0, 0], [1, 0, 0, 0, 0, 1, 1, 0], [1, 1, 0, 0, 0, 1, 1, 1], [0, 1, 0, 0, 0, 1, 0, 1]], np.float32)
+    hdr = ("ply\nformat %s 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\n"
+           "property float nz\nproperty float u\nproperty float v\nelement face 1\nproperty list uchar int vertex_indices\nend_header\n")
+    with open(path, "wb") as f:
+        if binary:
+            f.write((hdr % "binary_little_endian").encode())
+            f.write(verts.tobytes()); f.write(bytes([4])); f.write(np.array([0, 1, 2, 3], np.int32).tobytes())
+        else:
+            f.write((hdr % "ascii").encode())
+            for v in verts:
+                f.write((" ".join("%g" % x for x in v) + "\n").encode())
+            f.write(b"4 0 1 2 3\n")
+
+
+@pytest.mark.parametrize("binary_ply", [False, True])
+def test_pbrt_scene_ingest(tmp_path, binary_ply):
+    from PIL import Image
+    Image.fromarray(_jpeg_image(16, 8, "RGB", 2), "RGB").save(str(tmp_path / "wood.jpg"), "JPEG")
+    _write_ply(str(tmp_path / "leaf.ply"), binary_ply)
+    (tmp_path / "more.pbrt").write_text('Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 9  1 0 9  0 1 9]\n')
+    (tmp_path / "scene.pbrt").write_text(PBRT_SCENE)
+    d = host.load_scene(str(tmp_path / "scene.pbrt"))
+    t, m = d.tris, d.materials
+    # world shapes in file order, then the instances: quad (2), rotated tri (1), glass tri (1), included mirror tri (1), 2 x leaf quad (2 x 2)
+    assert t.size == 9 and list(t["matId"]) == [1, 1, 2, 3, 4, 5, 5, 5, 5]
+    assert m.size == 6                                                       # default + 5 in order of first use
+    assert [int(x) for x in m["type"][1:]] == [wire.BXDF.DIFFUSE, wire.BXDF.GGX_ROUGH_REFLECTION, wire.BXDF.IDEAL_DIELECTRIC,
+                                              wire.BXDF.IDEAL_REFLECTION, wire.BXDF.GLOSSY]
+    P = lambda i, v: np.array([t[i][v]["p"][k] for k in "xyz"])
+    assert np.allclose(P(0, "v0"), [1, 2, 3]) and np.allclose(P(0, "v2"), [2, 3, 3])                    # Translate
+    assert np.allclose(P(2, "v0"), [0, 2, 0], atol=1e-5) and np.allclose(P(2, "v1"), [-2, 0, 0], atol=1e-5)   # Scale then Rotate 90 about z
+    n2 = np.array([t[2]["v0"]["n"][k] for k in "xyz"])
+    assert np.allclose(n2, [0, 0, 0.5], atol=1e-6)                                                      # inverse transpose, not renormalised
+    n3 = np.array([t[3]["v0"]["n"][k] for k in "xyz"])
+    assert np.allclose(n3, [0, 0, 1])                                                                   # no normals: flat normal
+    assert np.allclose(P(5, "v0"), [10, 0, 0]) and np.allclose(P(7, "v0"), [10, 5, 0])                 # instancing, CTM accumulates
+    assert np.allclose([t[6]["v1"]["t"]["x"], t[6]["v1"]["t"]["y"]], [1, 1])                           # quad fan 0-2-3 keeps the uvs
+    # materials: the reference's mapping
+    assert m[1]["map_Kd"] == 0 and d.texdesc.size == 1 and tuple(d.texdesc[0])[1:] == (16, 8)
+    assert np.isclose(m[2]["Ni"], (0.2 + 0.9 + 1.1) / 3) and np.isclose(m[2]["Ns"], (1 - 0.2) * 5000) and np.allclose([m[2]["Ks"][k] for k in "xyz"], [3, 2.3, 1.8])
+    assert np.isclose(m[3]["Ni"], 1.33) and np.allclose([m[3]["Ks"][k] for k in "xyz"], 0.9)
+    assert np.allclose([m[4]["Ks"][k] for k in "xyz"], 0.9)
+    assert np.isclose(m[5]["Ns"], (1 - 0.05) * 5000) and np.isclose(m[5]["Ni"], 1.5) and np.allclose([m[5]["Kd"][k] for k in "xyz"], [.1, .6, .1])
+    assert d.world_up == (0.0, 0.0, 1.0)                                                                # Z-up camera frame
+    host.build_bvh(d, "sbvh")                                                                           # and it feeds the rest of the host path
+    assert d.nodes.size >= 1
+
+
+def test_pbrt_errors(tmp_path):
+    (tmp_path / "a.pbrt").write_text('WorldBegin\nShape "sphere"\nWorldEnd\n')
+    with pytest.raises(RuntimeError, match="without triangle"):
+        host.load_scene(str(tmp_path / "a.pbrt"))
+    (tmp_path / "b.pbrt").write_text('WorldBegin\nAttributeEnd\n')
+    with pytest.raises(RuntimeError, match="unmatched"):
+        host.load_scene(str(tmp_path / "b.pbrt"))
+    (tmp_path / "c.pbrt").write_text('WorldBegin\nShape "plymesh" "string filename" "missing.ply"\n')
+    with pytest.raises(RuntimeError, match="cannot open"):
+        host.load_scene(str(tmp_path / "c.pbrt"))
