@@ -85,7 +85,7 @@ struct flx_ctx {
     uint32_t *pinnedIdx = nullptr; int nextIdxSlot = 0;
     std::vector<PendingCounters> pending;
     // profiling
-    bool profile = false;
+    int profile = 0;              // 0 off | 1 time every kernel | 2 the traversal kernels + span | 3 the extension kernel only
     hipEvent_t spanStart = nullptr;             // pending FLX_K_TRACE_SPAN start (recorded in flx_wf_extend)
     std::vector<PendingEvent> events;
     std::vector<hipEvent_t> eventPool;
@@ -112,8 +112,15 @@ static hipEvent_t getEvent(flx_ctx *c)
 }
 struct ScopedTimer {
     flx_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-    ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) { if (c->profile) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); } }
-    ~ScopedTimer() { if (c->profile) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
+    bool on;
+    // profile level 1 = every kernel, 2 = the two traversal kernels + their span, 3 = the extension kernel only
+    // (each event pair costs a few us of stream time)
+    ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream)
+    {
+        on = c->profile == 1 || (c->profile == 2 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW)) || (c->profile == 3 && k == FLX_K_EXTEND);
+        if (on) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); }
+    }
+    ~ScopedTimer() { if (on) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
 };
 
 static uint32_t localPixels(const flx_ctx *c)
@@ -448,7 +455,7 @@ int flx_wf_extend(flx_ctx *c)
     READY(c);
     KEEP_CHAIN(c);
     if (c->overlap) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));      // "everything enqueued before the extension kernel"
-    if (c->profile) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
+    if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
@@ -479,7 +486,7 @@ int flx_wf_shadow(flx_ctx *c)
     hipStream_t s = c->stream;
     if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, early ? c->evPostLogic : c->evPreExt, 0)); }
     hipEvent_t earlyStart = nullptr;
-    if (c->profile && early) { earlyStart = getEvent(c); (void)hipEventRecord(earlyStart, s); }
+    if ((c->profile == 1 || c->profile == 2) && early) { earlyStart = getEvent(c); (void)hipEventRecord(earlyStart, s); }
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
@@ -489,7 +496,7 @@ int flx_wf_shadow(flx_ctx *c)
     }
     LAUNCHED(c);
     if (overlapped) { HIPCHK(c, hipEventRecord(c->evShadow, s)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadow, 0)); }
-    if (c->profile && overlapped && c->spanStart) {
+    if ((c->profile == 1 || c->profile == 2) && overlapped && c->spanStart) {
         // span of the two traversals: from the earlier start (the shadow kernel's when it ran ahead) to the join
         hipEvent_t b = getEvent(c); (void)hipEventRecord(b, c->stream);
         if (earlyStart) { c->eventPool.push_back(c->spanStart); c->spanStart = earlyStart; earlyStart = nullptr; }
@@ -617,7 +624,7 @@ int flx_copy_pixels_to_device(flx_ctx *c, void *dst)
 }
 
 // ---- measurement
-int flx_profile_enable(flx_ctx *c, int on) { c->profile = on != 0; return 0; }
+int flx_profile_enable(flx_ctx *c, int on) { c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
 int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
 int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
 int flx_trace_stats_enable(flx_ctx *c, int on) { c->statsOn = on != 0; return 0; }
