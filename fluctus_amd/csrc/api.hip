@@ -28,7 +28,8 @@ void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
 void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
 void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
 void launch_mk_splat(hipStream_t, const State &, const Frame &, const flx_render_params &, uint32_t *, int);
-void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t);
+void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t, uint32_t);
+void launch_bump_extension(hipStream_t, uint32_t *, uint32_t);
 }
 
 using namespace flxd;
@@ -69,6 +70,7 @@ struct flx_ctx {
     int compact = 1;            // use the 32-byte compact node records when the tree allows it
     int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
     int refillThresh = 40;
+    int eagerBump = 0;          // A/B: bump the extension counter right after raygen / materials (option eager_bump)
     int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
     std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
@@ -166,6 +168,9 @@ extern "C" {
 // flx_wf_shadow run ahead on the second stream; the few calls that are safe to run ahead of restore them (KEEP_CHAIN).
 #define MUTATES(c) do { (c)->overlapOK = false; (c)->logicChainPrev = (c)->logicChain; (c)->logicChain = false; } while (0)
 #define KEEP_CHAIN(c) do { (c)->logicChain = (c)->logicChainPrev; } while (0)
+// lazy extension counter (flx_device.h): make counters[EXTENSION] in memory current before anything outside the
+// raygen / material / extension / end-of-iteration kernels looks at it or overwrites the source counters
+static void flushExt(flx_ctx *c) { if (c->qs.extPend) { launch_bump_extension(c->stream, c->qs.counters, c->qs.extPend); c->qs.extPend = 0; } }
 const char *flx_last_error(flx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
@@ -448,8 +453,8 @@ uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 #define READY(c) do { MUTATES(c); NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
-int flx_wf_reset(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
-int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_reset(flx_ctx *c) { READY(c); flushExt(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } c->qs.extPend |= 1u << FLX_Q_RAYGEN; if (c->eagerBump) flushExt(c); LAUNCHED(c); return 0; }
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
@@ -508,12 +513,16 @@ int flx_wf_shadow(flx_ctx *c)
 int flx_wf_logic(flx_ctx *c, int first)
 {
     READY(c);
+    flushExt(c);                                       // logic's scan overwrites the source-queue counters
     { ScopedTimer t(c, FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first); }
     LAUNCHED(c);
     if (c->overlap == 2) { HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream)); c->logicChain = true; }
     return 0;
 }
-int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); } LAUNCHED(c); return 0; }
+int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); }
+    c->qs.extPend |= c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
+    if (c->eagerBump) flushExt(c);
+    LAUNCHED(c); return 0; }
 int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
 // ---- microkernel integrator
@@ -536,12 +545,13 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
 }
 int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
-int flx_clear_queues(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+int flx_clear_queues(flx_ctx *c) { MUTATES(c); c->qs.extPend = 0; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
     NEED(c, out32, "flx_get_counters_async: null");
     HIPCHK(c, hipSetDevice(c->device));
+    flushExt(c);
     if ((int)c->pending.size() >= c->pinnedSlots) { c->err = "too many outstanding counter reads; call flx_finish"; return 1; }
     int slot = c->nextSlot; c->nextSlot = (c->nextSlot + 1) % c->pinnedSlots;
     HIPCHK(c, hipMemcpyAsync(&c->pinned[slot], c->qs.counters, 32, hipMemcpyDeviceToHost, c->stream));
@@ -589,7 +599,8 @@ int flx_pixel_index_reset(flx_ctx *c)
 int flx_end_iteration_async(flx_ctx *c)
 {
     READY(c);
-    launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels);
+    launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend);
+    c->qs.extPend = 0;
     LAUNCHED(c);
     return 0;
 }
@@ -690,6 +701,7 @@ int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
 int flx_set_counters(flx_ctx *c, const void *in32)
 {
     MUTATES(c);
+    c->qs.extPend = 0;                                  // the caller's counters are complete
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->qs.counters, in32, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -706,6 +718,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
         return 0;
     }
+    if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     if (name && strcmp(name, "stream_inner_min") == 0 && value >= 1 && value <= 64) { c->streamInnerMin = value; return 0; }
     if (name && strcmp(name, "stream_refill") == 0 && value >= 1 && value <= 64) { c->streamRefill = value; return 0; }

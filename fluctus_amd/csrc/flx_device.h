@@ -44,6 +44,8 @@ struct State {
 struct Queues {
     uint32_t *q[FLX_NUM_QUEUES];
     uint32_t *counters;           // 8 x u32 (flx_queue_counters)
+    uint32_t extPend;             // lazy extension counter: bit q set = counters[q] entries were appended to the extension queue
+                                  // but counters[EXTENSION] has not been bumped yet (see ext_len)
 };
 
 #define FLX_LEAF_BIT 0x80000000u
@@ -158,6 +160,16 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 // extension counter as left by the previous call; a 1-thread kernel adds the appended total
 // afterwards (stream order).  The extension queue thus is the concatenation
 // [raygen | diffuse | glossy | ggxRefl | ggxRefr | delta] in source order: deterministic.
-// (k_bump_extension / launch_bump_extension live in misc.hip)
+// The bump itself is LAZY: the host remembers which source queues were appended (Queues::extPend) and every kernel
+// that needs the extension-queue length adds those lengths on the fly (ext_len); the 1-thread bump kernel
+// (k_bump_extension, misc.hip) only runs when someone outside these kernels looks at the counter
+// (flx_get_counters_async, flx_wf_logic without a preceding clear, ...).  The steady-state loop never launches it.
+
+__device__ __forceinline__ uint32_t ext_len(const Queues &qs)
+{
+    uint32_t n = qs.counters[FLX_Q_EXTENSION];
+    if (qs.extPend) for (int q = 0; q < FLX_NUM_QUEUES; q++) if (qs.extPend & (1u << q)) n += qs.counters[q];
+    return n;
+}
 
 } // namespace flxd

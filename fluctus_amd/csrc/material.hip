@@ -76,7 +76,7 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
     }
     if (active) {
         // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)
-        uint32_t base = qs.counters[FLX_Q_EXTENSION];
+        uint32_t base = ext_len(qs);
         for (int q = FLX_Q_DIFFUSE; q < FLX_NUM_QUEUES; q++) if (earlierMask & (1u << q)) base += qs.counters[q];
         qs.q[FLX_Q_EXTENSION][base + idx] = gid;
     }
@@ -128,10 +128,9 @@ void launch_materials(hipStream_t s, const State &st, const Queues &qs, const Sc
             uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK + 4;
             hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc);
         }
-        launch_bump_extension(s, qs.counters, D | G | RL | RR | DL);
+        (void)G; (void)RL; (void)RR; (void)DL; (void)D;            // the host records the appended queues (flx_wf_materials): lazy bump
     } else {
         launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_ALL, 0u);
-        launch_bump_extension(s, qs.counters, 1u << FLX_Q_DIFFUSE);
     }
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), seed));
         init_path_state(st, gid, 2.0f * p.worldRadius);
     }
-    if (active) qs.q[FLX_Q_EXTENSION][qs.counters[FLX_Q_EXTENSION] + gd] = gid;   // extBase + index (see flx_device.h)
+    if (active) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;   // extBase + index (see flx_device.h)
 }
 
 __global__ void k_bump_extension(uint32_t *counters, uint32_t srcMask)
@@ -184,19 +184,20 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const flo
     st.phase[gid] = __float_as_uint(R(FLX_COL_PHASE));
 }
 
-__global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels)
+__global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend)
 {
     const uint32_t i = threadIdx.x;
     if (i < 8u) {
-        const uint32_t v = counters[i];
+        uint32_t v = counters[i];
+        if (i == FLX_Q_EXTENSION) for (int q = 0; q < FLX_NUM_QUEUES; q++) if (extPend & (1u << q)) v += counters[q];     // lazy extension counter
         totals[i] += v;
         if (i == FLX_Q_RAYGEN) *cursor = (uint32_t)(((unsigned long long)*cursor + v) % localPixels);
         counters[i] = 0u;
     }
 }
-void launch_end_iteration(hipStream_t s, uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels)
+void launch_end_iteration(hipStream_t s, uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend)
 {
-    hipLaunchKernelGGL(k_end_iteration, dim3(1), dim3(64), 0, s, counters, totals, cursor, localPixels);
+    hipLaunchKernelGGL(k_end_iteration, dim3(1), dim3(64), 0, s, counters, totals, cursor, localPixels, extPend);
 }
 
 void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
@@ -207,7 +208,6 @@ void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame 
 void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
 {
     hipLaunchKernelGGL(k_raygen, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
-    hipLaunchKernelGGL(k_bump_extension, dim3(1), dim3(64), 0, s, qs.counters, 1u << FLX_Q_RAYGEN);
 }
 void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
 {

@@ -27,7 +27,7 @@ template <bool STATS>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int xcdRemap)
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
-    const uint32_t qlen = qs.counters[FLX_Q_EXTENSION];
+    const uint32_t qlen = ext_len(qs);
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x, xcdRemap);
     const uint32_t idx = blk * TRACE_BLOCK + threadIdx.x;
     if (idx >= qlen) return;

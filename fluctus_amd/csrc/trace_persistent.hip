@@ -35,7 +35,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_trace_persiste
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
     const int QID = ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION;
-    const uint32_t qlen = qs.counters[QID];
+    const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
     const uint32_t *queue = qs.q[QID];
     const uint32_t shardLen = ((qlen + 7u) / 8u + 63u) & ~63u;       // contiguous eighth, wave-aligned
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, STREAM_MIN_WAVES) void k_trace_stream(
 {
     __shared__ uint32_t s_stack[LDS_LEVELS * TRACE_BLOCK];
     const int QID = ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION;
-    const uint32_t qlen = qs.counters[QID];
+    const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
     const uint32_t *queue = qs.q[QID];
     uint32_t chunk = (qlen + gridDim.x - 1u) / gridDim.x;
     if (chunk < 64u) chunk = 64u;
