@@ -132,9 +132,7 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--trace-mode", type=int, default=0)
     ap.add_argument("--overlap", type=int, default=2)
-    ap.add_argument("--compact-nodes", type=int, default=1)
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
-    ap.add_argument("--refill-thresh", type=int, default=40)
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
     ap.add_argument("--kernel-timing", type=int, default=3, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel (roofline) only")
@@ -176,8 +174,6 @@ def main():
         c_.set_option("xcd_remap", args.xcd_remap)
         c_.set_option("trace_mode", args.trace_mode)
         c_.set_option("overlap", args.overlap)
-        c_.set_option("compact_nodes", args.compact_nodes)
-        c_.set_option("refill_thresh", args.refill_thresh)
         c_.set_option("node_layout", args.node_layout)
         c_.set_option("eager_bump", args.eager_bump)
         c_.set_option("stream_refill", args.stream_refill)

@@ -12,8 +12,6 @@
 namespace flxd {
 void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
-void launch_extend_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
-void launch_shadow_persistent(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, uint32_t *, int, int, uint32_t);
 void launch_extend_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, float4 *, int, int, uint32_t, bool);
 void launch_shadow_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int, int, uint32_t, bool);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
@@ -67,9 +65,7 @@ struct flx_ctx {
     uint32_t *pinnedMk = nullptr; std::vector<std::pair<void *, int>> pendingMk; int nextMkSlot = 0;
     bool statsOn = false;
     int xcdRemap = 0;           // 1: each XCD gets a contiguous eighth of the queue (measured slower: round-robin keeps all XCDs on the same part of the tree)
-    int compact = 1;            // use the 32-byte compact node records when the tree allows it
-    int traceMode = 0;          // 0 = one thread per queue entry, 1 = persistent while-while waves
-    int refillThresh = 40;
+    int traceMode = 0;          // 0 = one thread per queue entry | 2, 3 = static-chunk refill variants (trace_stream.hip)
     int eagerBump = 0;          // A/B: bump the extension counter right after raygen / materials (option eager_bump)
     int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
     std::vector<void *> aovAllocs;
@@ -79,7 +75,6 @@ struct flx_ctx {
     int streamWavesExt = 28, streamWavesShadow = 28;   // trace_mode 2: grid = CUs x this many waves
     float4 *hitraw = nullptr;   // trace_mode 2: {t,u,v,tri} per extension-queue slot
     int numCUs = 256;
-    uint32_t *fetch = nullptr;  // 2 x 8 shard counters for the persistent trace kernels
     // owned device allocations
     std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs;
     // async counter read-back
@@ -212,7 +207,6 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if (dalloc(c, c->fixedAllocs, &c->spill2, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
     if (dalloc(c, c->fixedAllocs, &c->hitraw, (size_t)num_tasks)) return fail("hipMalloc(hitraw)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->fetch, 16)) return fail("hipMalloc(fetch)", hipErrorOutOfMemory);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     if (dalloc(c, c->fixedAllocs, &c->stats, 16)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->stats, 0, 128, c->stream);
@@ -351,33 +345,6 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         }
     }
     NEED(c, ok, "flx_upload_scene: malformed node array");
-    // 2b. compact 32-byte records (see flx_device.h / trace.hip): valid only if, on every face of every inner node, at
-    // least one child carries the node's own plane bit for bit -- true for any BVH whose boxes are exact unions.
-    std::vector<CNode> cnodes;
-    {
-        bool compactable = ninner > 0 && nrecords <= CREF_INDEX_MASK && nidx <= CREF_INDEX_MASK;
-        if (compactable) { cnodes.resize(nrecords); memset(cnodes.data(), 0, cnodes.size() * sizeof(CNode)); }
-        for (size_t i = 0; i < nnodes && compactable; i++) {
-            if (nodes[i].nPrims != 0) continue;
-            const flx_node &P = nodes[i], &L = nodes[i + 1], &R = nodes[nodes[i].iStartOrRight];
-            const float pp[6] = {P.bmin.x, P.bmin.y, P.bmin.z, P.bmax.x, P.bmax.y, P.bmax.z};
-            const float lp[6] = {L.bmin.x, L.bmin.y, L.bmin.z, L.bmax.x, L.bmax.y, L.bmax.z};
-            const float rp[6] = {R.bmin.x, R.bmin.y, R.bmin.z, R.bmax.x, R.bmax.y, R.bmax.z};
-            const BNode &b = bnodes[innerId[i]];
-            CNode &cn = cnodes[innerId[i]];
-            uint32_t lf = 0, rf = 0;
-            for (int f = 0; f < 6; f++) {
-                const bool lo = memcmp(&lp[f], &pp[f], 4) == 0, ro = memcmp(&rp[f], &pp[f], 4) == 0;
-                if (!lo && !ro) { compactable = false; break; }
-                if (lo) lf |= 1u << (CREF_FLAG_SHIFT + f);
-                if (ro) rf |= 1u << (CREF_FLAG_SHIFT + f);
-                cn.inner[f] = lo ? rp[f] : lp[f];           // the non-owner's plane (either one when both own it)
-            }
-            cn.left = (b.left & FLX_LEAF_BIT) | lf | (b.left & CREF_INDEX_MASK);
-            cn.right = (b.right & FLX_LEAF_BIT) | rf | (b.right & CREF_INDEX_MASK);
-        }
-        if (!compactable) cnodes.clear();
-    }
     // 3. shading records per ORIGINAL triangle index
     std::vector<ShadeRec> shade(ntris);
     for (size_t i = 0; i < ntris; i++) {
@@ -391,12 +358,10 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     freeAll(c->sceneAllocs);
-    CNode *dC = nullptr;
     BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX;
     if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size() + 1) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
         dalloc(c, c->sceneAllocs, &dTri, ntris) || dalloc(c, c->sceneAllocs, &dM, nmat) || dalloc(c, c->sceneAllocs, &dD, ntex) || dalloc(c, c->sceneAllocs, &dX, texbytes + 4))
         return 1;
-    if (!cnodes.empty()) { if (dalloc(c, c->sceneAllocs, &dC, cnodes.size())) return 1; HIPCHK(c, hipMemcpy(dC, cnodes.data(), cnodes.size() * sizeof(CNode), hipMemcpyHostToDevice)); }
     HIPCHK(c, hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dS, shade.data(), shade.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
@@ -404,7 +369,6 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     HIPCHK(c, hipMemcpy(dM, materials, nmat * sizeof(flx_material), hipMemcpyHostToDevice));
     if (ntex) HIPCHK(c, hipMemcpy(dD, texdesc, ntex * sizeof(flx_texdesc), hipMemcpyHostToDevice));
     if (texbytes) HIPCHK(c, hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
-    c->sc.cnodes = c->compact ? dC : nullptr; c->sc.cnodesAll = dC;
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
     return 0;
@@ -463,8 +427,7 @@ int flx_wf_extend(flx_ctx *c)
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
-        if (c->traceMode == 1) launch_extend_persistent(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->fetch, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
-        else if (c->traceMode >= 2) launch_extend_stream(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->hitraw, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesExt), c->traceMode == 3);
+        if (c->traceMode >= 2) launch_extend_stream(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->hitraw, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesExt), c->traceMode == 3);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -495,8 +458,7 @@ int flx_wf_shadow(flx_ctx *c)
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
-        if (c->traceMode == 1) launch_shadow_persistent(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->fetch + 8, c->refillThresh, c->numCUs, (c->numTasks + 63) / 64);
-        else if (c->traceMode >= 2) launch_shadow_stream(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesShadow), c->traceMode == 3);
+        if (c->traceMode >= 2) launch_shadow_stream(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesShadow), c->traceMode == 3);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -711,8 +673,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
-    if (name && strcmp(name, "compact_nodes") == 0 && (value == 0 || value == 1)) { c->compact = value; c->sc.cnodes = value ? c->sc.cnodesAll : nullptr; return 0; }
-    if (name && strcmp(name, "trace_mode") == 0 && value >= 0 && value <= 3) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 2 || value == 3)) { c->traceMode = value; return 0; }
     if (name && strcmp(name, "denoiser") == 0 && (value == 0 || value == 1)) {
         MUTATES(c);
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
@@ -724,7 +685,6 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "stream_refill") == 0 && value >= 1 && value <= 64) { c->streamRefill = value; return 0; }
     if (name && strcmp(name, "stream_waves_ext") == 0 && value >= 1 && value <= 64) { c->streamWavesExt = value; return 0; }
     if (name && strcmp(name, "stream_waves_shadow") == 0 && value >= 1 && value <= 64) { c->streamWavesShadow = value; return 0; }
-    if (name && strcmp(name, "refill_thresh") == 0 && value >= 1 && value <= 64) { c->refillThresh = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;
 }

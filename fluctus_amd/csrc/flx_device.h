@@ -57,15 +57,6 @@ struct BNode {                    // 64 B, 64-B aligned
     uint32_t pad[2];
 };
 
-// Compact inner-node record (32 B), usable when the node's own box is known (see trace.hip): per face the plane of
-// the child that does NOT share the parent's plane; child references carry 6 ownership bits each.
-#define CREF_FLAG_SHIFT 25
-#define CREF_INDEX_MASK 0x01FFFFFFu               // 25-bit BNode index / triangle slot (33 M)
-struct CNode {
-    float inner[6];               // minx, miny, minz, maxx, maxy, maxz of the non-owning child
-    uint32_t left, right;         // FLX_LEAF_BIT | ownership bits << 25 | index
-};
-
 struct TriRec {                   // 48 B: three float4
     float4 a;                     // v0.xyz, triangle index (int bits)
     float4 b;                     // v1.xyz, leaf count in the first record of a leaf run (int bits)
@@ -81,8 +72,6 @@ struct ShadeRec {                 // 64 B: four float4
 
 struct Scene {
     const BNode *bnodes;
-    const CNode *cnodes;          // nullptr when the tree is not compactable (a child box not inside-touching its parent) or switched off
-    const CNode *cnodesAll;       // the uploaded array (option compact_nodes toggles cnodes)
     const TriRec *trirecs;
     const ShadeRec *shade;
     const flx_triangle *tris;     // reference-layout triangles (tangent frames for normal maps only)

@@ -15,10 +15,6 @@ namespace flxd {
 #ifndef TRACE_MIN_WAVES
 #define TRACE_MIN_WAVES 1        // __launch_bounds__ 2nd argument (min waves per SIMD -> VGPR cap)
 #endif
-#ifndef TRACE_COMPACT
-#define TRACE_COMPACT 0           // 1: lossless 32-byte compact node records for nodes entered straight from their parent (2 loads instead
-                                 // of 4).  Bit-exact, but measured 5 % SLOWER (78 VGPRs -> 6 waves/SIMD, decode ALU, two load paths); A/B only
-#endif
 #ifndef SHADOW_MIN_WAVES
 #define SHADOW_MIN_WAVES 1         // 8 fits (64 VGPRs, no spill) but measures the same as 7
 #endif
@@ -109,14 +105,11 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks, int 
 
 // One ray through the tree, reference visit order (near child first, leaf triangles in index order).
 //
-// Loop shape ("while-while", TRACE_LOOP 1): the inner `while` descends AND pops, so a lane leaves it only when it stands
-// on a leaf or has finished; the wave then intersects all pending leaves together.  The obvious single loop
-// (TRACE_LOOP 0: if inner / else leaf / pop at the bottom) is structurised by the compiler into descend-only inner
-// loops with the pop in the outer loop: every lane that dead-ends waits for the deepest descent of the wave --
-// measured 95 inner trips per wave against 46.5 for the wave's longest ray (bench.py roofline.simd_efficiency).
-#ifndef TRACE_LOOP
-#define TRACE_LOOP 1
-#endif
+// Loop shape ("while-while"): the inner `while` descends AND pops, so a lane leaves it only when it stands on a leaf or
+// has finished; the wave then intersects all pending leaves together.  The obvious single loop (if inner / else leaf /
+// pop at the bottom) is structurised by the compiler into descend-only inner loops with the pop in the outer loop:
+// every lane that dead-ends waits for the deepest descent of the wave -- measured 95 inner trips per wave against 76
+// for this shape and 46.5 for the wave's longest ray (bench.py roofline.simd_efficiency).
 #define FLX_RAY_DONE 0xFFFFFFFFu                  // leaf bit set: never taken for an inner node
 
 template <bool ANY_HIT, bool STATS>
@@ -130,7 +123,6 @@ __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f
     const f3 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     int sp = 0;
     uint32_t cur = sc.rootRef;
-#if TRACE_LOOP == 1
     for (;;) {
         FLX_WAVE_TICK(0);
         while (!(cur & FLX_LEAF_BIT)) {
@@ -179,97 +171,6 @@ __device__ __forceinline__ bool traverse(const Scene &sc, Stack &stk, f3 orig, f
         cur = stk.pop(--sp);
     }
     return false;
-#else
-#if TRACE_COMPACT
-    bool boxKnown = false;
-    float pmin[3] = {0.0f, 0.0f, 0.0f}, pmax[3] = {0.0f, 0.0f, 0.0f};
-#endif
-    for (;;) {
-        FLX_WAVE_TICK(0);
-        if (!(cur & FLX_LEAF_BIT)) {
-            FLX_WAVE_TICK(1);
-            float lmin[3], lmax[3], rmin[3], rmax[3];
-            uint32_t left, right;
-#if TRACE_COMPACT
-            if (boxKnown) {
-                // Reached straight from the parent, whose test just produced this node's own box (pmin, pmax): a 32-byte
-                // record suffices.  The union of the two child boxes IS the parent box, so on every one of the six faces at
-                // least one child carries the parent's plane; the record stores only the other child's plane per face plus
-                // two ownership bits (in the spare high bits of the child references).  Lossless: the 12 decoded floats are
-                // bit-identical to the full record's, 2 vector loads instead of 4.
-                const float4 *cp = reinterpret_cast<const float4 *>(sc.cnodes + cur);
-                const float4 c0 = cp[0], c1 = cp[1];
-                const uint32_t lr = __float_as_uint(c1.z), rr = __float_as_uint(c1.w);
-                const float in[6] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y};
-                const float par[6] = {pmin[0], pmin[1], pmin[2], pmax[0], pmax[1], pmax[2]};
-                float lp[6], rp[6];
-#pragma unroll
-                for (int f = 0; f < 6; f++) {
-                    lp[f] = (lr & (1u << (CREF_FLAG_SHIFT + f))) ? par[f] : in[f];
-                    rp[f] = (rr & (1u << (CREF_FLAG_SHIFT + f))) ? par[f] : in[f];
-                }
-                lmin[0] = lp[0]; lmin[1] = lp[1]; lmin[2] = lp[2]; lmax[0] = lp[3]; lmax[1] = lp[4]; lmax[2] = lp[5];
-                rmin[0] = rp[0]; rmin[1] = rp[1]; rmin[2] = rp[2]; rmax[0] = rp[3]; rmax[1] = rp[4]; rmax[2] = rp[5];
-                left = (lr & FLX_LEAF_BIT) | (lr & CREF_INDEX_MASK); right = (rr & FLX_LEAF_BIT) | (rr & CREF_INDEX_MASK);
-            } else
-#endif
-            {
-                const float4 *np = reinterpret_cast<const float4 *>(sc.bnodes + cur);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                lmin[0] = n0.x; lmin[1] = n0.y; lmin[2] = n0.z; lmax[0] = n0.w; lmax[1] = n1.x; lmax[2] = n1.y;
-                rmin[0] = n1.z; rmin[1] = n1.w; rmin[2] = n2.x; rmax[0] = n2.y; rmax[1] = n2.z; rmax[2] = n2.w;
-                left = __float_as_uint(n3.x); right = __float_as_uint(n3.y);
-            }
-            if (STATS) nInner++;
-            float lnear, rnear;
-            bool lh = slab(lmin, lmax, orig, dinv, tbest, &lnear);
-            bool rh = slab(rmin, rmax, orig, dinv, tbest, &rnear);
-            if (lh && rh) {
-                uint32_t closer = left, farther = right;
-                bool goRight = rnear < lnear;
-                if (goRight) { closer = right; farther = left; }
-                stk.push(sp++, farther);
-                cur = closer;
-#if TRACE_COMPACT
-                for (int k = 0; k < 3; k++) { pmin[k] = goRight ? rmin[k] : lmin[k]; pmax[k] = goRight ? rmax[k] : lmax[k]; }
-                boxKnown = sc.cnodes != nullptr;
-#endif
-                continue;
-            } else if (lh || rh) {
-                cur = lh ? left : right;
-#if TRACE_COMPACT
-                for (int k = 0; k < 3; k++) { pmin[k] = lh ? lmin[k] : rmin[k]; pmax[k] = lh ? lmax[k] : rmax[k]; }
-                boxKnown = sc.cnodes != nullptr;
-#endif
-                continue;
-            }
-        } else {
-            uint32_t slot = cur & ~FLX_LEAF_BIT;
-            const float4 *tp = reinterpret_cast<const float4 *>(sc.trirecs + slot);
-            float4 a = tp[0], b = tp[1], c = tp[2];
-            int count = __float_as_int(b.w);
-            FLX_WAVE_TICK(2);
-            for (int k = 0;;) {
-                FLX_WAVE_TICK(3);
-                if (STATS) nTri++;
-                float t, u, v;
-                if (moller_trumbore(orig, dir, ld3(a), ld3(b), ld3(c), &t, &u, &v) && t > 0.0f && t < tbest) {
-                    if (ANY_HIT) return true;
-                    tbest = t; ubest = u; vbest = v; tribest = __float_as_int(a.w);
-                }
-                if (++k >= count) break;
-                tp += 3;
-                a = tp[0]; b = tp[1]; c = tp[2];
-            }
-        }
-        if (sp == 0) break;
-        cur = stk.pop(--sp);
-#if TRACE_COMPACT
-        boxKnown = false;                      // a popped node's own box is not at hand: full record
-#endif
-    }
-    return false;
-#endif
 #undef FLX_WAVE_TICK
 }
 

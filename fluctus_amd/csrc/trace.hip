@@ -10,8 +10,6 @@
 //  * the traversal stack lives in LDS, laid out [level][lane] so a wave's push/pop is one
 //    conflict-free ds_write_b32/ds_read_b32 (the reference's `uint stack[64]` is private memory,
 //    i.e. scratch on a wave64 machine); levels >= LDS_LEVELS spill to a global side buffer;
-//  * optional (-DTRACE_COMPACT=1, measured slower, off): a node entered straight from its parent can be read from a
-//    lossless 32-byte compact record (2 loads instead of 4); only popped nodes and the root need the full record;
 //  * the current node is kept in a register ("push farther, continue with closer"), which is the
 //    same visit order as the reference's push-both-pop-one;
 //  * triangles are 48-B position-only records in leaf order; normals/uvs/matId are fetched once

@@ -153,14 +153,14 @@ int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
 int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);
 int flx_set_counters(flx_ctx *ctx, const void *in32);
 /* tuning knobs (kernel variants, all bit-identical in their results); see DESIGN.md 4.1.  Unknown names fail.
- *   trace_mode        0 thread per ray (default) | 1 persistent waves, atomic refill | 2 static-chunk refill, threshold
- *                     descent | 3 static-chunk refill, unified work items
+ *   trace_mode        0 thread per ray (default) | 2 static-chunk refill, threshold descent | 3 static-chunk refill,
+ *                     unified work items (both measured slower, kept for A/B: DESIGN.md 4.1)
  *   overlap           0 serial | 1 flx_wf_shadow directly after flx_wf_extend runs concurrently with it on a second stream |
  *                     2 (default) as 1, and it starts as soon as `logic` is done when only raygen / materials / extend
  *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip)
  *   node_layout       1 (default) sibling-pair record numbering | 0 DFS numbering; takes effect at the next flx_upload_scene
  *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
- *   compact_nodes, xcd_remap, refill_thresh, stream_refill, stream_inner_min, stream_waves_ext, stream_waves_shadow */
+ *   xcd_remap, eager_bump, stream_refill, stream_inner_min, stream_waves_ext, stream_waves_shadow: A/B knobs */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus

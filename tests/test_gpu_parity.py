@@ -15,16 +15,15 @@ from fluctus_amd import host, wire, driver
 pytestmark = pytest.mark.gpu
 
 
-TRACE_MODE = {"mode": 1, "thresh": 40, "xcd": 0, "compact": 1, "overlap": 2}
+TRACE_MODE = {"mode": 0, "thresh": 24, "xcd": 0, "overlap": 2}
 
 
-# (trace_mode, refill threshold, xcd_remap, compact_nodes, overlap): every kernel variant and stream schedule must give the same bits
-@pytest.fixture(params=[(0, 40, 0, 1, 2), (0, 40, 1, 0, 1), (0, 40, 0, 1, 0), (1, 40, 0, 1, 2), (1, 8, 0, 0, 1), (2, 24, 0, 1, 2), (2, 1, 0, 1, 0), (2, 64, 0, 0, 1),
-                        (3, 24, 0, 1, 2), (3, 1, 0, 1, 1), (3, 64, 0, 0, 0)],
-                ids=["thread-per-ray", "thread-per-ray-xcdremap-fullnodes-overlap1", "thread-per-ray-serial", "persistent-t40", "persistent-t8-fullnodes-overlap1",
-                     "stream-refill24", "stream-refill1-serial", "stream-refill64-overlap1", "flow-refill24", "flow-refill1-overlap1", "flow-refill64-serial"], autouse=True)
+# (trace_mode, refill threshold, xcd_remap, overlap): every kernel variant and stream schedule must give the same bits
+@pytest.fixture(params=[(0, 24, 0, 2), (0, 24, 1, 1), (0, 24, 0, 0), (2, 24, 0, 2), (2, 1, 0, 0), (2, 64, 0, 1), (3, 24, 0, 2), (3, 1, 0, 1), (3, 64, 0, 0)],
+                ids=["thread-per-ray", "thread-per-ray-xcdremap-overlap1", "thread-per-ray-serial", "stream-refill24", "stream-refill1-serial",
+                     "stream-refill64-overlap1", "flow-refill24", "flow-refill1-overlap1", "flow-refill64-serial"], autouse=True)
 def trace_mode(request):
-    TRACE_MODE["mode"], TRACE_MODE["thresh"], TRACE_MODE["xcd"], TRACE_MODE["compact"], TRACE_MODE["overlap"] = request.param
+    TRACE_MODE["mode"], TRACE_MODE["thresh"], TRACE_MODE["xcd"], TRACE_MODE["overlap"] = request.param
     yield
 
 
@@ -33,11 +32,9 @@ def _ctxs(d, p, n, env=None):
     from oracle.binding import OracleContext
     g, o = HipContext(n), OracleContext(n, threads=8)
     g.set_option("trace_mode", TRACE_MODE["mode"])
-    g.set_option("refill_thresh", TRACE_MODE["thresh"])
     g.set_option("stream_refill", TRACE_MODE["thresh"])
     g.set_option("overlap", TRACE_MODE["overlap"])
     g.set_option("xcd_remap", TRACE_MODE["xcd"])
-    g.set_option("compact_nodes", TRACE_MODE["compact"])
     for c in (g, o):
         c.upload_scene(d)
         if env is not None:
