@@ -186,10 +186,23 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
     c->st.numTasks = num_tasks;
+#if STATE_LAYOUT
+    {   // three arrays of 64-byte lines (flx_device.h)
+        static const int group[S_NUM_REC][2] = {/*ORIG*/ {0, 0}, /*DIR*/ {0, 1}, /*HITP*/ {1, 0}, /*HITN*/ {1, 1}, /*HITUV*/ {1, 2}, /*THR*/ {0, 2},
+                                                /*EI*/ {0, 3}, /*SHO*/ {2, 0}, /*SHD*/ {2, 1}, /*LBSDF*/ {2, 2}, /*LEMIT*/ {2, 3}, /*LT*/ {1, 3}};
+        float4 *line[3];
+        for (int g = 0; g < 3; g++) {
+            if (dalloc(c, c->fixedAllocs, &line[g], N * 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
+            (void)hipMemsetAsync(line[g], 0, N * 4 * sizeof(float4), c->stream);
+        }
+        for (int r = 0; r < S_NUM_REC; r++) c->st.rec[r] = line[group[r][0]] + group[r][1];
+    }
+#else
     for (int r = 0; r < S_NUM_REC; r++) {
         if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
         (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
     }
+#endif
     if (dalloc(c, c->fixedAllocs, &c->st.phase, N) || dalloc(c, c->fixedAllocs, &c->mkStats, 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->st.phase, 0, N * 4, c->stream); (void)hipMemsetAsync(c->mkStats, 0, 16, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->st.blocked, N) || dalloc(c, c->fixedAllocs, &c->st.pickProb, N) || dalloc(c, c->fixedAllocs, &c->st.firstDiffuse, N))

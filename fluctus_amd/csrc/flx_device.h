@@ -32,8 +32,18 @@ using namespace flx;
 
 enum { S_ORIG = 0, S_DIR, S_HITP, S_HITN, S_HITUV, S_THR, S_EI, S_SHO, S_SHD, S_LBSDF, S_LEMIT, S_LT, S_NUM_REC };
 
+// STATE_LAYOUT 0: twelve separate arrays (pure SoA of float4).  1: three arrays of 64-byte LINES, four records each --
+//   A {ORIG, DIR, THR, EI}  B {HITP, HITN, HITUV, LT}  C {SHO, SHD, LBSDF, LEMIT}
+// -- so that the kernels that reach the state through a queue (raygen, materials, both traversals) touch one line per
+// group instead of one line per record.  Record r of path gid is rec[r][gid * STATE_STRIDE] in both layouts.
+#ifndef STATE_LAYOUT
+#define STATE_LAYOUT 0
+#endif
+#define STATE_STRIDE (STATE_LAYOUT ? 4 : 1)
+
 struct State {
-    float4 *rec[S_NUM_REC];       // each numTasks float4
+    float4 *rec[S_NUM_REC];       // record r of path gid: rec[r] + gid * STATE_STRIDE
+    __host__ __device__ __forceinline__ float4 *at(int r, uint32_t gid) const { return rec[r] + (size_t)gid * STATE_STRIDE; }
     uint32_t *blocked;            // shadowRayBlocked
     float *pickProb;              // lastLightPickProb
     uint32_t *firstDiffuse;       // carried for export parity only

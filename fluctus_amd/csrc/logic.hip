@@ -52,12 +52,12 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
     uint32_t member = 0u;
 
     if (gid < maxId) {
-        const float4 thr = rd4(st.rec[S_THR] + gid);
-        const float4 d4 = rd4(st.rec[S_DIR] + gid);
-        const float4 o4 = rd4(st.rec[S_ORIG] + gid);
-        const float4 hn = rd4(st.rec[S_HITN] + gid);
-        const float4 huv = rd4(st.rec[S_HITUV] + gid);
-        const float4 ei4 = rd4(st.rec[S_EI] + gid);
+        const float4 thr = rd4(st.at(S_THR, gid));
+        const float4 d4 = rd4(st.at(S_DIR, gid));
+        const float4 o4 = rd4(st.at(S_ORIG, gid));
+        const float4 hn = rd4(st.at(S_HITN, gid));
+        const float4 huv = rd4(st.at(S_HITUV, gid));
+        const float4 ei4 = rd4(st.at(S_EI, gid));
         uint32_t seed = __float_as_uint(thr.w);
         const uint32_t len = __float_as_uint(d4.w);
         const f3 rayOrig = ld3(o4), rayDir = ld3(d4);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
 
         if (hitI < 0 && !terminate) {                                 // implicit environment sample, :84-107
             float weight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.rec[S_LT] + gid).w) != 0u;
+            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
             f3 bg = mk3(0.0f);
             if (p.useEnvMap && (len == 1u || p.sampleImpl)) bg = eval_env_dir(sc, rayDir) * p.envMapStrength;
             if (p.sampleImpl && p.sampleExpl && p.useEnvMap && len > 1u && !lastSpecular) {
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             terminate = true;
         } else if (p.useAreaLight && (hflags & 1u) && !terminate) {   // implicit area-light sample, :111-131
             float misWeight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.rec[S_LT] + gid).w) != 0u;
-            const f3 hitP = ld3(rd4(st.rec[S_HITP] + gid));
+            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
+            const f3 hitP = ld3(rd4(st.at(S_HITP, gid)));
             if (p.sampleExpl && len > 1u && !lastSpecular) {
                 float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
                 float directPdfW = pdf_a_to_w(directPdfA, length(hitP - rayOrig), dot(normalize(-rayDir), hitN));
@@ -108,10 +108,10 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
 
         // consume the light sample generated at the previous vertex (:135-156)
         if (st.blocked[gid] == 0u) {
-            const float4 le = rd4(st.rec[S_LEMIT] + gid);
-            const float4 lb = rd4(st.rec[S_LBSDF] + gid);
-            const float4 lt = rd4(st.rec[S_LT] + gid);
-            const float directPdfW = rd4(st.rec[S_SHD] + gid).w;
+            const float4 le = rd4(st.at(S_LEMIT, gid));
+            const float4 lb = rd4(st.at(S_LBSDF, gid));
+            const float4 lt = rd4(st.at(S_LT, gid));
+            const float directPdfW = rd4(st.at(S_SHD, gid)).w;
             const float lightPickProb = st.pickProb[gid];
             const float cosTh = le.w, bsdfPdfW = lb.w;
             float weight = 1.0f;
@@ -126,15 +126,15 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                 unsafeAtomicAdd(px + 0, Ei.x); unsafeAtomicAdd(px + 1, Ei.y);
                 unsafeAtomicAdd(px + 2, Ei.z); unsafeAtomicAdd(px + 3, 1.0f);
             }
-            wr4(st.rec[S_EI] + gid, mk4(Ei, ei4.w));
-            wr4(st.rec[S_THR] + gid, mk4u(T, seed));
+            wr4(st.at(S_EI, gid), mk4(Ei, ei4.w));
+            wr4(st.at(S_THR, gid), mk4u(T, seed));
             member = 1u;
         } else {
             const flx_material mat = sc.materials[hitMat];            // :180-184
             hitN = tangent_space_normal(sc, hitN, hitUV, hitI, mat.map_N);
             const bool backface = dot(hitN, rayDir) > 0.0f;
             if (backface) hitN = hitN * -1.0f;
-            const f3 hitP = ld3(rd4(st.rec[S_HITP] + gid));
+            const f3 hitP = ld3(rd4(st.at(S_HITP, gid)));
             const f3 orig = hitP - 1e-3f * rayDir;
             if (fr.aovNormal) {                                       // denoiser features, :186-209
                 const uint32_t pixIdx = __float_as_uint(ei4.w);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     unsafeAtomicAdd(px + 0, albedo.x); unsafeAtomicAdd(px + 1, albedo.y); unsafeAtomicAdd(px + 2, albedo.z); unsafeAtomicAdd(px + 3, 1.0f);
                 }
             }
-            wr4(st.rec[S_HITN] + gid, mk4u(hitN, (hflags & 1u) | (backface ? 2u : 0u)));   // :212-213
+            wr4(st.at(S_HITN, gid), mk4u(hitN, (hflags & 1u) | (backface ? 2u : 0u)));   // :212-213
 
             if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {    // next event estimation, :217-302
                 uint32_t den = p.useEnvMap + p.useAreaLight; if (den < 1u) den = 1u;
@@ -164,9 +164,9 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     L = normalize(L);
                     const float cosTh = fmaxf_(0.0f, dot(L, hitN));
                     const f3 envMapLi = eval_env_dir(sc, L) * p.envMapStrength;
-                    wr4(st.rec[S_SHO] + gid, mk4(orig, lenL));
-                    wr4(st.rec[S_SHD] + gid, mk4(L, directPdfW));
-                    wr4(st.rec[S_LEMIT] + gid, mk4(envMapLi, cosTh));
+                    wr4(st.at(S_SHO, gid), mk4(orig, lenL));
+                    wr4(st.at(S_SHD, gid), mk4(L, directPdfW));
+                    wr4(st.at(S_LEMIT, gid), mk4(envMapLi, cosTh));
                     st.pickProb[gid] = envMapProb;
                     member |= 2u;
                 }
@@ -185,9 +185,9 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     if (cosLight > 0.0f) {
                         const float directPdfW = pdf_a_to_w(directPdfA, lenL, cosLight);
                         const float cosTh = fmaxf_(0.0f, dot(L, hitN));
-                        wr4(st.rec[S_SHO] + gid, mk4(orig, lenL));
-                        wr4(st.rec[S_SHD] + gid, mk4(L, directPdfW));
-                        wr4(st.rec[S_LEMIT] + gid, mk4(V(p.areaLight.E), cosTh));
+                        wr4(st.at(S_SHO, gid), mk4(orig, lenL));
+                        wr4(st.at(S_SHD, gid), mk4(L, directPdfW));
+                        wr4(st.at(S_LEMIT, gid), mk4(V(p.areaLight.E), cosTh));
                         st.pickProb[gid] = lightPickProb;
                         member |= 2u;
                     } else {
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     }
                 }
             }
-            wr4(st.rec[S_EI] + gid, mk4(Ei, ei4.w));
-            wr4(st.rec[S_THR] + gid, mk4u(T, seed));
+            wr4(st.at(S_EI, gid), mk4(Ei, ei4.w));
+            wr4(st.at(S_THR, gid), mk4u(T, seed));
             (void)Tdirty;
             member |= material_list(mat.type, p.wfSeparateQueues) << 2;
         }

@@ -26,12 +26,12 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
     uint32_t gid = 0;
     if (active) {
         gid = qs.q[queueId][idx];
-        const float4 thr = rd4(st.rec[S_THR] + gid);
-        const float4 hp = rd4(st.rec[S_HITP] + gid);
-        const float4 hn = rd4(st.rec[S_HITN] + gid);
-        const float4 huv = rd4(st.rec[S_HITUV] + gid);
-        const float4 d4 = rd4(st.rec[S_DIR] + gid);
-        const float4 sd = rd4(st.rec[S_SHD] + gid);
+        const float4 thr = rd4(st.at(S_THR, gid));
+        const float4 hp = rd4(st.at(S_HITP, gid));
+        const float4 hn = rd4(st.at(S_HITN, gid));
+        const float4 huv = rd4(st.at(S_HITUV, gid));
+        const float4 d4 = rd4(st.at(S_DIR, gid));
+        const float4 sd = rd4(st.at(S_SHD, gid));
         uint32_t seed = __float_as_uint(thr.w);
         SurfHit h; h.P = ld3(hp); h.N = ld3(hn); h.uv = mk2(huv.x, huv.y);
         const bool backface = (__float_as_uint(hn.w) & 2u) != 0u;
@@ -68,11 +68,11 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
         else newT = oldT * bsdf * costh / pdfW;
         const f3 orig = h.P + 1e-4f * newDir;                      // :53
 
-        wr4(st.rec[S_LBSDF] + gid, mk4(bsdfNEE, bsdfPdfW));
-        wr4(st.rec[S_LT] + gid, mk4u(oldT, FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u));
-        wr4(st.rec[S_THR] + gid, mk4u(newT, seed));
-        wr4(st.rec[S_ORIG] + gid, mk4(orig, pdfW));
-        wr4(st.rec[S_DIR] + gid, mk4(newDir, d4.w));
+        wr4(st.at(S_LBSDF, gid), mk4(bsdfNEE, bsdfPdfW));
+        wr4(st.at(S_LT, gid), mk4u(oldT, FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u));
+        wr4(st.at(S_THR, gid), mk4u(newT, seed));
+        wr4(st.at(S_ORIG, gid), mk4(orig, pdfW));
+        wr4(st.at(S_DIR, gid), mk4(newDir, d4.w));
     }
     if (active) {
         // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)

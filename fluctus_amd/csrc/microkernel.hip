@@ -37,11 +37,11 @@ __global__ __launch_bounds__(256) void k_mk_reset(State st, Frame fr, flx_render
         reinterpret_cast<float4 *>(fr.aovAlbedo)[gid] = make_float4(0.1f, 0.1f, 0.1f, 0.0f);
     }
     st.phase[gid] = MK_GENERATE_CAMERA_RAY;
-    float4 ei = rd4(st.rec[S_EI] + gid); wr4(st.rec[S_EI] + gid, make_float4(0.0f, 0.0f, 0.0f, ei.w));
-    wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), gid));                                           // T = 1, seed = gid
-    float4 d = rd4(st.rec[S_DIR] + gid); d.w = __uint_as_float(0u); wr4(st.rec[S_DIR] + gid, d);      // pathLen
-    float4 lt = rd4(st.rec[S_LT] + gid); lt.w = __uint_as_float(1u); wr4(st.rec[S_LT] + gid, lt);     // lastSpecular
-    float4 o = rd4(st.rec[S_ORIG] + gid); o.w = 1.0f; wr4(st.rec[S_ORIG] + gid, o);                   // lastPdfW
+    float4 ei = rd4(st.at(S_EI, gid)); wr4(st.at(S_EI, gid), make_float4(0.0f, 0.0f, 0.0f, ei.w));
+    wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), gid));                                           // T = 1, seed = gid
+    float4 d = rd4(st.at(S_DIR, gid)); d.w = __uint_as_float(0u); wr4(st.at(S_DIR, gid), d);      // pathLen
+    float4 lt = rd4(st.at(S_LT, gid)); lt.w = __uint_as_float(1u); wr4(st.at(S_LT, gid), lt);     // lastSpecular
+    float4 o = rd4(st.at(S_ORIG, gid)); o.w = 1.0f; wr4(st.at(S_ORIG, gid), o);                   // lastPdfW
     st.firstDiffuse[gid] = 0u;
 }
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_mk_raygen(State st, flx_render_params p
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= mk_limit(st, p) || st.phase[gid] != MK_GENERATE_CAMERA_RAY) return;
-    const float4 thr = rd4(st.rec[S_THR] + gid);
+    const float4 thr = rd4(st.at(S_THR, gid));
     uint32_t seed = __float_as_uint(thr.w);
     float x = (float)(gid % p.width), y = (float)(gid / p.width);
     x += rand01(&seed);
@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void k_mk_raygen(State st, flx_render_params p
     const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
     rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
     rayDirection = normalize(fp - rayOrig);
-    const float4 o = rd4(st.rec[S_ORIG] + gid), d = rd4(st.rec[S_DIR] + gid);
-    wr4(st.rec[S_ORIG] + gid, mk4(rayOrig, o.w));
-    wr4(st.rec[S_DIR] + gid, mk4(rayDirection, d.w));
-    wr4(st.rec[S_THR] + gid, mk4u(ld3(thr), seed));
+    const float4 o = rd4(st.at(S_ORIG, gid)), d = rd4(st.at(S_DIR, gid));
+    wr4(st.at(S_ORIG, gid), mk4(rayOrig, o.w));
+    wr4(st.at(S_DIR, gid), mk4(rayDirection, d.w));
+    wr4(st.at(S_THR, gid), mk4u(ld3(thr), seed));
     st.phase[gid] = MK_RT_NEXT_VERTEX;
 }
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
     const bool active = gid < mk_limit(st, p) && st.phase[gid] == MK_RT_NEXT_VERTEX;
     bool primary = false;
     if (active) {
-        const float4 o4 = rd4(st.rec[S_ORIG] + gid), d4 = rd4(st.rec[S_DIR] + gid);
+        const float4 o4 = rd4(st.at(S_ORIG, gid)), d4 = rd4(st.at(S_DIR, gid));
         const f3 orig = ld3(o4), dir = ld3(d4);
         Stack stk; stk.lds = s_stack + threadIdx.x; stk.stride = totalThreads; stk.spill = spill + gid;
         float t = FLX_FLT_MAX, u = 0.0f, v = 0.0f; int tri = -1; uint32_t a = 0, b = 0;
@@ -98,14 +98,14 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
             tu = uv.x; tv = uv.y; matId = __float_as_int(sd.w);
         }
         if (p.sampleImpl && p.useAreaLight && light_quad(p.areaLight, orig, dir, &t)) { flags = 1u; P = orig + t * dir; N = V(p.areaLight.N); tri = 0; matId = 0; }
-        const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(&st.rec[S_HITN][gid])[3]) & 2u;
-        wr4(st.rec[S_HITP] + gid, mk4(P, t));
-        wr4(st.rec[S_HITN] + gid, mk4u(N, flags | keep));
-        wr4(st.rec[S_HITUV] + gid, make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+        const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;
+        wr4(st.at(S_HITP, gid), mk4(P, t));
+        wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
+        wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
         uint32_t len = __float_as_uint(d4.w);
         primary = len == 0u;
         len += 1u;
-        wr4(st.rec[S_DIR] + gid, mk4u(dir, len));
+        wr4(st.at(S_DIR, gid), mk4u(dir, len));
         if (fr.aovNormal && len == 1u) {                             // first-hit normal, camera space (src/mk_next_vertex.cl:59-69); thread = pixel
             float4 *px = reinterpret_cast<float4 *>(fr.aovNormal) + gid;
             const float4 acc = *px; const f3 n = camera_space_normal(p, N);
@@ -116,20 +116,20 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
             f3 bg = mk3(0.0f);
             if (p.useEnvMap && (len == 1u || p.sampleImpl)) bg = eval_env_dir(sc, dir) * p.envMapStrength;
             float weight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.rec[S_LT] + gid).w) != 0u;
+            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
             if (p.sampleImpl && p.sampleExpl && p.useEnvMap && len > 1u && !lastSpecular) {
                 const float lightPickProb = 1.0f;
                 const float directPdfW = env_map_pdf(sc, dir);
                 const float actualPdfW = o4.w;
                 weight = (actualPdfW * lightPickProb) / (actualPdfW * lightPickProb + directPdfW);
             }
-            const f3 T = ld3(rd4(st.rec[S_THR] + gid));
-            const float4 ei = rd4(st.rec[S_EI] + gid);
-            wr4(st.rec[S_EI] + gid, mk4(ld3(ei) + weight * T * bg, ei.w));
+            const f3 T = ld3(rd4(st.at(S_THR, gid)));
+            const float4 ei = rd4(st.at(S_EI, gid));
+            wr4(st.at(S_EI, gid), mk4(ld3(ei) + weight * T * bg, ei.w));
             phase = MK_SPLAT_SAMPLE;
         } else if (flags & 1u) {                                     // implicit area-light hit (:94-113)
             float misWeight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.rec[S_LT] + gid).w) != 0u;
+            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
             if (p.sampleExpl && len > 1u && !lastSpecular) {
                 const float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
                 const float directPdfW = pdf_a_to_w(directPdfA, length(P - orig), dot(normalize(-dir), N));
@@ -137,9 +137,9 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_next_vertex(State st, Scene sc,
                 const float lastPdfW = o4.w;
                 misWeight = lastPdfW / (lastPdfW + directPdfW * lightPickProb);
             }
-            const f3 T = ld3(rd4(st.rec[S_THR] + gid));
-            const float4 ei = rd4(st.rec[S_EI] + gid);
-            wr4(st.rec[S_EI] + gid, mk4(ld3(ei) + T * misWeight * V(p.areaLight.E), ei.w));
+            const f3 T = ld3(rd4(st.at(S_THR, gid)));
+            const float4 ei = rd4(st.at(S_EI, gid));
+            wr4(st.at(S_EI, gid), mk4(ld3(ei) + T * misWeight * V(p.areaLight.E), ei.w));
             phase = MK_SPLAT_SAMPLE;
         }
         st.phase[gid] = phase;
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc,
     const bool active = gid < mk_limit(st, p) && st.phase[gid] == MK_SAMPLE_BSDF;
     uint32_t nShadow = 0;
     if (active) {
-        const float4 thr = rd4(st.rec[S_THR] + gid);
+        const float4 thr = rd4(st.at(S_THR, gid));
         uint32_t seed = __float_as_uint(thr.w);
-        const float4 d4 = rd4(st.rec[S_DIR] + gid), hp = rd4(st.rec[S_HITP] + gid), hn = rd4(st.rec[S_HITN] + gid), huv = rd4(st.rec[S_HITUV] + gid);
+        const float4 d4 = rd4(st.at(S_DIR, gid)), hp = rd4(st.at(S_HITP, gid)), hn = rd4(st.at(S_HITN, gid)), huv = rd4(st.at(S_HITUV, gid));
         const f3 rayDir = ld3(d4);
         const int hitI = __float_as_int(huv.z);
         const flx_material &gm = sc.materials[__float_as_int(huv.w)];
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc,
             const float4 acc = *px; const f3 al = mat_float3(sc, V(gm.Kd), h.uv, gm.map_Kd);
             *px = make_float4(acc.x + al.x, acc.y + al.y, acc.z + al.z, acc.w + 1.0f);
         }
-        f3 Ei = ld3(rd4(st.rec[S_EI] + gid));
-        const float eiw = rd4(st.rec[S_EI] + gid).w;
+        f3 Ei = ld3(rd4(st.at(S_EI, gid)));
+        const float eiw = rd4(st.at(S_EI, gid)).w;
         const f3 T = ld3(thr);
         Stack stk; stk.lds = s_stack + threadIdx.x; stk.stride = totalThreads; stk.spill = spill + gid;
         if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(m.type)) {         // next event estimation, both lights (src/mk_sample_bsdf.cl:62-141)
@@ -237,11 +237,11 @@ __global__ __launch_bounds__(MK_BLOCK) void k_mk_sample_bsdf(State st, Scene sc,
         if (pdfW == 0.0f || is_zero(bsdf)) terminate = true;
         const f3 newT = T * bsdf * costh / pdfW;
         orig = h.P + 1e-4f * newDir;
-        wr4(st.rec[S_EI] + gid, mk4(Ei, eiw));
-        wr4(st.rec[S_THR] + gid, mk4u(newT, seed));
-        wr4(st.rec[S_ORIG] + gid, mk4(orig, pdfW));
-        wr4(st.rec[S_DIR] + gid, mk4(newDir, d4.w));
-        float4 lt = rd4(st.rec[S_LT] + gid); lt.w = __uint_as_float(FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u); wr4(st.rec[S_LT] + gid, lt);
+        wr4(st.at(S_EI, gid), mk4(Ei, eiw));
+        wr4(st.at(S_THR, gid), mk4u(newT, seed));
+        wr4(st.at(S_ORIG, gid), mk4(orig, pdfW));
+        wr4(st.at(S_DIR, gid), mk4(newDir, d4.w));
+        float4 lt = rd4(st.at(S_LT, gid)); lt.w = __uint_as_float(FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u); wr4(st.at(S_LT, gid), lt);
         st.phase[gid] = terminate ? MK_SPLAT_SAMPLE : MK_RT_NEXT_VERTEX;
     }
     for (int o = 32; o > 0; o >>= 1) nShadow += __shfl_xor(nShadow, o, 64);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_mk_splat(State st, Frame fr, flx_render
     const bool inRange = gid < mk_limit(st, p);
     const bool active = inRange && (preview || st.phase[gid] == MK_SPLAT_SAMPLE);
     if (active) {
-        const float4 ei = rd4(st.rec[S_EI] + gid);
+        const float4 ei = rd4(st.at(S_EI, gid));
         float4 *px = reinterpret_cast<float4 *>(fr.pixels) + gid;
         if (preview) *px = make_float4(ei.x, ei.y, ei.z, 0.0f);     // alpha 0 => overwritten by the next real sample
         else {
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256) void k_mk_splat(State st, Frame fr, flx_render
             if (prev.w > 0.0f) { col.x += prev.x; col.y += prev.y; col.z += prev.z; col.w += prev.w; }
             *px = col;
         }
-        wr4(st.rec[S_EI] + gid, make_float4(0.0f, 0.0f, 0.0f, ei.w));
-        const float4 thr = rd4(st.rec[S_THR] + gid); wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), __float_as_uint(thr.w)));
-        float4 d = rd4(st.rec[S_DIR] + gid); d.w = __uint_as_float(0u); wr4(st.rec[S_DIR] + gid, d);
+        wr4(st.at(S_EI, gid), make_float4(0.0f, 0.0f, 0.0f, ei.w));
+        const float4 thr = rd4(st.at(S_THR, gid)); wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), __float_as_uint(thr.w)));
+        float4 d = rd4(st.at(S_DIR, gid)); d.w = __uint_as_float(0u); wr4(st.at(S_DIR, gid), d);
         if (!preview) st.firstDiffuse[gid] = 0u;
         st.phase[gid] = MK_GENERATE_CAMERA_RAY;
     }

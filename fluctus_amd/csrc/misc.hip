@@ -11,18 +11,18 @@ namespace flxd {
 // Everything a (re)generated path starts from (src/wf_reset.cl:30-60 == src/wf_raygen.cl:77-96)
 __device__ __forceinline__ void init_path_state(const State &st, uint32_t gid, float shadowLen)
 {
-    wr4(st.rec[S_LBSDF] + gid, make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // lastBsdf, lastPdfImplicit
-    wr4(st.rec[S_LEMIT] + gid, make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // lastEmission, lastCosTh
-    wr4(st.rec[S_HITP] + gid, make_float4(0.0f, 0.0f, 0.0f, FLX_FLT_MAX)); // EMPTY_HIT
-    wr4(st.rec[S_HITN] + gid, make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // N, areaLightHit = backfaceHit = 0
-    wr4(st.rec[S_HITUV] + gid, make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1)));
+    wr4(st.at(S_LBSDF, gid), make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // lastBsdf, lastPdfImplicit
+    wr4(st.at(S_LEMIT, gid), make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // lastEmission, lastCosTh
+    wr4(st.at(S_HITP, gid), make_float4(0.0f, 0.0f, 0.0f, FLX_FLT_MAX)); // EMPTY_HIT
+    wr4(st.at(S_HITN, gid), make_float4(0.0f, 0.0f, 0.0f, 0.0f));       // N, areaLightHit = backfaceHit = 0
+    wr4(st.at(S_HITUV, gid), make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1)));
     st.pickProb[gid] = 1.0f;
     st.blocked[gid] = 1u;
     st.firstDiffuse[gid] = 0u;
     // records with members reset() leaves alone are read-modify-written
-    float4 sho = rd4(st.rec[S_SHO] + gid); sho.w = shadowLen; wr4(st.rec[S_SHO] + gid, sho);
-    float4 shd = rd4(st.rec[S_SHD] + gid); shd.w = 0.0f; wr4(st.rec[S_SHD] + gid, shd);            // lastPdfDirect
-    float4 lt = rd4(st.rec[S_LT] + gid); lt.w = __uint_as_float(1u); wr4(st.rec[S_LT] + gid, lt);  // lastSpecular
+    float4 sho = rd4(st.at(S_SHO, gid)); sho.w = shadowLen; wr4(st.at(S_SHO, gid), sho);
+    float4 shd = rd4(st.at(S_SHD, gid)); shd.w = 0.0f; wr4(st.at(S_SHD, gid), shd);            // lastPdfDirect
+    float4 lt = rd4(st.at(S_LT, gid)); lt.w = __uint_as_float(1u); wr4(st.at(S_LT, gid), lt);  // lastSpecular
 }
 
 __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame fr, flx_render_params p, uint32_t n)
@@ -38,10 +38,10 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame
     }
     if (gid >= st.numTasks) return;
     init_path_state(st, gid, 2.0f * p.worldRadius);
-    wr4(st.rec[S_EI] + gid, make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)));     // Ei, pixelIndex
-    wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), gid));                                   // T, seed = gid
-    float4 o = rd4(st.rec[S_ORIG] + gid); o.w = 1.0f; wr4(st.rec[S_ORIG] + gid, o);          // lastPdfW
-    float4 d = rd4(st.rec[S_DIR] + gid); d.w = __uint_as_float(0u); wr4(st.rec[S_DIR] + gid, d);   // pathLen
+    wr4(st.at(S_EI, gid), make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)));     // Ei, pixelIndex
+    wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), gid));                                   // T, seed = gid
+    float4 o = rd4(st.at(S_ORIG, gid)); o.w = 1.0f; wr4(st.at(S_ORIG, gid), o);          // lastPdfW
+    float4 d = rd4(st.at(S_DIR, gid)); d.w = __uint_as_float(0u); wr4(st.at(S_DIR, gid), d);   // pathLen
     qs.q[FLX_Q_RAYGEN][gid] = gid;
     if (gid == 0) qs.counters[FLX_Q_RAYGEN] = st.numTasks;
 }
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
     uint32_t gid = 0;
     if (active) {
         gid = qs.q[FLX_Q_RAYGEN][gd];
-        uint32_t seed = __float_as_uint(rd4(st.rec[S_THR] + gid).w);
+        uint32_t seed = __float_as_uint(rd4(st.at(S_THR, gid)).w);
         // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
         // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
         const uint32_t localIdx = (*fr.currPixelIdx + gd) % fr.localPixels;
@@ -82,10 +82,10 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
         rayDirection = normalize(fp - rayOrig);
 
-        wr4(st.rec[S_ORIG] + gid, mk4(rayOrig, 1.0f));                  // lastPdfW = 1
-        wr4(st.rec[S_DIR] + gid, mk4u(rayDirection, 0u));               // pathLen = 0
-        wr4(st.rec[S_EI] + gid, mk4u(mk3(0.0f), localIdx));
-        wr4(st.rec[S_THR] + gid, mk4u(mk3(1.0f), seed));
+        wr4(st.at(S_ORIG, gid), mk4(rayOrig, 1.0f));                  // lastPdfW = 1
+        wr4(st.at(S_DIR, gid), mk4u(rayDirection, 0u));               // pathLen = 0
+        wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), localIdx));
+        wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), seed));
         init_path_state(st, gid, 2.0f * p.worldRadius);
     }
     if (active) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;   // extBase + index (see flx_device.h)
@@ -138,20 +138,20 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *ou
     auto W = [&](int col, float v) { out[(size_t)col * N + gid] = v; };
     auto W3 = [&](int col, float4 v) { W(col, v.x); W(col + 1, v.y); W(col + 2, v.z); W(col + 3, 0.0f); };
     float4 r;
-    r = rd4(st.rec[S_ORIG] + gid); W3(FLX_COL_ORIG, r); W(FLX_COL_LAST_PDF_W, r.w);
-    r = rd4(st.rec[S_DIR] + gid); W3(FLX_COL_DIR, r); W(FLX_COL_PATH_LEN, r.w);
-    r = rd4(st.rec[S_SHO] + gid); W3(FLX_COL_SHADOW_ORIG, r); W(FLX_COL_SHADOW_LEN, r.w);
-    r = rd4(st.rec[S_SHD] + gid); W3(FLX_COL_SHADOW_DIR, r); W(FLX_COL_LAST_PDF_DIRECT, r.w);
-    r = rd4(st.rec[S_THR] + gid); W3(FLX_COL_T, r); W(FLX_COL_SEED, r.w);
-    r = rd4(st.rec[S_EI] + gid); W3(FLX_COL_EI, r); W(FLX_COL_PIXEL_INDEX, r.w);
-    r = rd4(st.rec[S_LBSDF] + gid); W3(FLX_COL_LAST_BSDF, r); W(FLX_COL_LAST_PDF_IMPLICIT, r.w);
-    r = rd4(st.rec[S_LEMIT] + gid); W3(FLX_COL_LAST_EMISSION, r); W(FLX_COL_LAST_COS_TH, r.w);
-    r = rd4(st.rec[S_LT] + gid); W3(FLX_COL_LAST_T, r); W(FLX_COL_LAST_SPECULAR, r.w);
-    r = rd4(st.rec[S_HITP] + gid); W3(FLX_COL_P, r); W(FLX_COL_HIT_T, r.w);
-    r = rd4(st.rec[S_HITN] + gid); W3(FLX_COL_N, r);
+    r = rd4(st.at(S_ORIG, gid)); W3(FLX_COL_ORIG, r); W(FLX_COL_LAST_PDF_W, r.w);
+    r = rd4(st.at(S_DIR, gid)); W3(FLX_COL_DIR, r); W(FLX_COL_PATH_LEN, r.w);
+    r = rd4(st.at(S_SHO, gid)); W3(FLX_COL_SHADOW_ORIG, r); W(FLX_COL_SHADOW_LEN, r.w);
+    r = rd4(st.at(S_SHD, gid)); W3(FLX_COL_SHADOW_DIR, r); W(FLX_COL_LAST_PDF_DIRECT, r.w);
+    r = rd4(st.at(S_THR, gid)); W3(FLX_COL_T, r); W(FLX_COL_SEED, r.w);
+    r = rd4(st.at(S_EI, gid)); W3(FLX_COL_EI, r); W(FLX_COL_PIXEL_INDEX, r.w);
+    r = rd4(st.at(S_LBSDF, gid)); W3(FLX_COL_LAST_BSDF, r); W(FLX_COL_LAST_PDF_IMPLICIT, r.w);
+    r = rd4(st.at(S_LEMIT, gid)); W3(FLX_COL_LAST_EMISSION, r); W(FLX_COL_LAST_COS_TH, r.w);
+    r = rd4(st.at(S_LT, gid)); W3(FLX_COL_LAST_T, r); W(FLX_COL_LAST_SPECULAR, r.w);
+    r = rd4(st.at(S_HITP, gid)); W3(FLX_COL_P, r); W(FLX_COL_HIT_T, r.w);
+    r = rd4(st.at(S_HITN, gid)); W3(FLX_COL_N, r);
     const uint32_t fl = __float_as_uint(r.w);
     W(FLX_COL_AREA_LIGHT_HIT, __uint_as_float(fl & 1u)); W(FLX_COL_BACKFACE, __uint_as_float((fl >> 1) & 1u));
-    r = rd4(st.rec[S_HITUV] + gid); W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
+    r = rd4(st.at(S_HITUV, gid)); W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
     W(FLX_COL_PHASE, __uint_as_float(st.phase[gid]));
     W(FLX_COL_SHADOW_BLOCKED, __uint_as_float(st.blocked[gid]));
     W(FLX_COL_LAST_PICK_PROB, st.pickProb[gid]);
@@ -165,19 +165,19 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const flo
     if (gid >= N) return;
     auto R = [&](int col) { return in[(size_t)col * N + gid]; };
     auto R4 = [&](int col, int wcol) { return make_float4(R(col), R(col + 1), R(col + 2), R(wcol)); };
-    wr4(st.rec[S_ORIG] + gid, R4(FLX_COL_ORIG, FLX_COL_LAST_PDF_W));
-    wr4(st.rec[S_DIR] + gid, R4(FLX_COL_DIR, FLX_COL_PATH_LEN));
-    wr4(st.rec[S_SHO] + gid, R4(FLX_COL_SHADOW_ORIG, FLX_COL_SHADOW_LEN));
-    wr4(st.rec[S_SHD] + gid, R4(FLX_COL_SHADOW_DIR, FLX_COL_LAST_PDF_DIRECT));
-    wr4(st.rec[S_THR] + gid, R4(FLX_COL_T, FLX_COL_SEED));
-    wr4(st.rec[S_EI] + gid, R4(FLX_COL_EI, FLX_COL_PIXEL_INDEX));
-    wr4(st.rec[S_LBSDF] + gid, R4(FLX_COL_LAST_BSDF, FLX_COL_LAST_PDF_IMPLICIT));
-    wr4(st.rec[S_LEMIT] + gid, R4(FLX_COL_LAST_EMISSION, FLX_COL_LAST_COS_TH));
-    wr4(st.rec[S_LT] + gid, R4(FLX_COL_LAST_T, FLX_COL_LAST_SPECULAR));
-    wr4(st.rec[S_HITP] + gid, R4(FLX_COL_P, FLX_COL_HIT_T));
+    wr4(st.at(S_ORIG, gid), R4(FLX_COL_ORIG, FLX_COL_LAST_PDF_W));
+    wr4(st.at(S_DIR, gid), R4(FLX_COL_DIR, FLX_COL_PATH_LEN));
+    wr4(st.at(S_SHO, gid), R4(FLX_COL_SHADOW_ORIG, FLX_COL_SHADOW_LEN));
+    wr4(st.at(S_SHD, gid), R4(FLX_COL_SHADOW_DIR, FLX_COL_LAST_PDF_DIRECT));
+    wr4(st.at(S_THR, gid), R4(FLX_COL_T, FLX_COL_SEED));
+    wr4(st.at(S_EI, gid), R4(FLX_COL_EI, FLX_COL_PIXEL_INDEX));
+    wr4(st.at(S_LBSDF, gid), R4(FLX_COL_LAST_BSDF, FLX_COL_LAST_PDF_IMPLICIT));
+    wr4(st.at(S_LEMIT, gid), R4(FLX_COL_LAST_EMISSION, FLX_COL_LAST_COS_TH));
+    wr4(st.at(S_LT, gid), R4(FLX_COL_LAST_T, FLX_COL_LAST_SPECULAR));
+    wr4(st.at(S_HITP, gid), R4(FLX_COL_P, FLX_COL_HIT_T));
     const uint32_t fl = (__float_as_uint(R(FLX_COL_AREA_LIGHT_HIT)) ? 1u : 0u) | (__float_as_uint(R(FLX_COL_BACKFACE)) ? 2u : 0u);
-    wr4(st.rec[S_HITN] + gid, make_float4(R(FLX_COL_N), R(FLX_COL_N + 1), R(FLX_COL_N + 2), __uint_as_float(fl)));
-    wr4(st.rec[S_HITUV] + gid, make_float4(R(FLX_COL_UV), R(FLX_COL_UV + 1), R(FLX_COL_HIT_I), R(FLX_COL_MAT_ID)));
+    wr4(st.at(S_HITN, gid), make_float4(R(FLX_COL_N), R(FLX_COL_N + 1), R(FLX_COL_N + 2), __uint_as_float(fl)));
+    wr4(st.at(S_HITUV, gid), make_float4(R(FLX_COL_UV), R(FLX_COL_UV + 1), R(FLX_COL_HIT_I), R(FLX_COL_MAT_ID)));
     st.blocked[gid] = __float_as_uint(R(FLX_COL_SHADOW_BLOCKED));
     st.pickProb[gid] = R(FLX_COL_LAST_PICK_PROB);
     st.firstDiffuse[gid] = __float_as_uint(R(FLX_COL_FIRST_DIFFUSE));

@@ -31,8 +31,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     if (idx >= qlen) return;
     const uint32_t gid = qs.q[FLX_Q_EXTENSION][idx];
 
-    const float4 o4 = rd4(st.rec[S_ORIG] + gid);
-    const float4 d4 = rd4(st.rec[S_DIR] + gid);
+    const float4 o4 = rd4(st.at(S_ORIG, gid));
+    const float4 d4 = rd4(st.at(S_DIR, gid));
     const f3 orig = ld3(o4), dir = ld3(d4);
 
     Stack stk;
@@ -68,12 +68,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
             tri = 0; matId = 0;
         }
     }
-    wr4(st.rec[S_DIR] + gid, mk4u(dir, __float_as_uint(d4.w) + 1u));          // pathLen += 1
-    wr4(st.rec[S_HITP] + gid, mk4(P, t));
+    wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(d4.w) + 1u));          // pathLen += 1
+    wr4(st.at(S_HITP, gid), mk4(P, t));
     // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
-    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(&st.rec[S_HITN][gid])[3]) & 2u;
-    wr4(st.rec[S_HITN] + gid, mk4u(N, flags | keep));
-    wr4(st.rec[S_HITUV] + gid, make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;
+    wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
+    wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
 
     if (STATS) {
         bool hitGeom = matId >= 0 && !(flags & 1u);
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, SHADOW_MIN_WAVES) void k_shadow(State 
     if (idx >= qlen) return;
     const uint32_t gid = qs.q[FLX_Q_SHADOW][idx];
 
-    const float4 o4 = rd4(st.rec[S_SHO] + gid);
-    const float4 d4 = rd4(st.rec[S_SHD] + gid);
+    const float4 o4 = rd4(st.at(S_SHO, gid));
+    const float4 d4 = rd4(st.at(S_SHD, gid));
     const f3 orig = ld3(o4), dir = ld3(d4);
     float lenL = o4.w;
 

@@ -81,8 +81,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, STREAM_MIN_WAVES) void k_trace_stream(
                     if (cur == FLX_RAY_DONE && my < end) {
                         const uint32_t gid = queue[my];
                         float4 o4, d4;
-                        if (!ANY_HIT) { o4 = rd4(st.rec[S_ORIG] + gid); d4 = rd4(st.rec[S_DIR] + gid); }
-                        else { o4 = rd4(st.rec[S_SHO] + gid); d4 = rd4(st.rec[S_SHD] + gid); }
+                        if (!ANY_HIT) { o4 = rd4(st.at(S_ORIG, gid)); d4 = rd4(st.at(S_DIR, gid)); }
+                        else { o4 = rd4(st.at(S_SHO, gid)); d4 = rd4(st.at(S_SHD, gid)); }
                         orig = ld3(o4); dir = ld3(d4);
                         dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                         tbest = ANY_HIT ? o4.w : FLX_FLT_MAX;
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, STREAM_MIN_WAVES) void k_trace_stream(
                 if (idle && my < end) {
                     const uint32_t gid = queue[my];
                     float4 o4, d4;
-                    if (!ANY_HIT) { o4 = rd4(st.rec[S_ORIG] + gid); d4 = rd4(st.rec[S_DIR] + gid); }
-                    else { o4 = rd4(st.rec[S_SHO] + gid); d4 = rd4(st.rec[S_SHD] + gid); }
+                    if (!ANY_HIT) { o4 = rd4(st.at(S_ORIG, gid)); d4 = rd4(st.at(S_DIR, gid)); }
+                    else { o4 = rd4(st.at(S_SHO, gid)); d4 = rd4(st.at(S_SHD, gid)); }
                     orig = ld3(o4); dir = ld3(d4);
                     dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                     tbest = ANY_HIT ? o4.w : FLX_FLT_MAX;
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, STREAM_MIN_WAVES) void k_trace_stream(
         for (uint32_t i = base + threadIdx.x; i < end; i += TRACE_BLOCK) {
             const uint32_t gid = queue[i];
             const float4 raw = hitraw[i];
-            const float4 o4 = rd4(st.rec[S_ORIG] + gid);
-            const float4 d4 = rd4(st.rec[S_DIR] + gid);
+            const float4 o4 = rd4(st.at(S_ORIG, gid));
+            const float4 d4 = rd4(st.at(S_DIR, gid));
             const f3 ro = ld3(o4), rdir = ld3(d4);
             float t = raw.x;
             const float u = raw.y, v = raw.z;
@@ -266,11 +266,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, STREAM_MIN_WAVES) void k_trace_stream(
                     flags = 1u; P = ro + t * rdir; N = V(p.areaLight.N); tri = 0; matId = 0;
                 }
             }
-            wr4(st.rec[S_DIR] + gid, mk4u(rdir, __float_as_uint(d4.w) + 1u));                 // pathLen += 1
-            wr4(st.rec[S_HITP] + gid, mk4(P, t));
-            const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(&st.rec[S_HITN][gid])[3]) & 2u;   // backfaceHit belongs to `logic`
-            wr4(st.rec[S_HITN] + gid, mk4u(N, flags | keep));
-            wr4(st.rec[S_HITUV] + gid, make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+            wr4(st.at(S_DIR, gid), mk4u(rdir, __float_as_uint(d4.w) + 1u));                 // pathLen += 1
+            wr4(st.at(S_HITP, gid), mk4(P, t));
+            const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;   // backfaceHit belongs to `logic`
+            wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
+            wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
         }
     }
 

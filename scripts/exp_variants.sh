@@ -7,5 +7,5 @@ for l in sys.stdin:
 "; }
 for v in ${VARIANTS}; do
   export FLX_HIP_LIB=$PWD/variants/libfluctus_hip_$v.so
-  run --overlap 0; run
+  run --overlap 0 --kernel-timing 1; run
 done
