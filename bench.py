@@ -86,7 +86,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(d, p, env, budget_s=12.0):
+def cpu_baseline(d, p, env, budget_s=12.0, force_kind=None):
     """CPU baseline on the host cores, bounded sample: the same scene / camera / parameters with 65 536 paths in flight,
     16 warm-up iterations, then whole iterations until `budget_s` seconds have elapsed.
 
@@ -97,7 +97,7 @@ def cpu_baseline(d, p, env, budget_s=12.0):
     from oracle.binding import OracleContext, RefContext, ref_available
     cores = usable_cores()
     n = 1 << 16
-    kind = "reference" if ref_available() and os.environ.get("FLX_CPU_BASELINE", "") != "port" else "port"
+    kind = force_kind or ("reference" if ref_available() and os.environ.get("FLX_CPU_BASELINE", "") != "port" else "port")
     c = RefContext(n, threads=cores) if kind == "reference" else OracleContext(n, threads=cores)
     c.upload_scene(d)
     c.upload_envmap(env)
@@ -353,6 +353,8 @@ def main():
             line["gather_ms"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
+            if line["cpu_baseline"]["kind"] == "reference":      # the oracle port beside it (order-preserving appends instead of per-path atomics)
+                line["cpu_baseline_port"] = cpu_baseline(d, p, env, budget_s=8.0, force_kind="port")
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
