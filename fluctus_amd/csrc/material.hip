@@ -14,7 +14,9 @@
 
 namespace flxd {
 
-#define MAT_BLOCK 256
+#ifndef MAT_BLOCK
+#define MAT_BLOCK 64            // one wave per block: interleaves best with the one-wave blocks of the concurrent shadow traversal (+1 %)
+#endif
 
 enum { USE_DIFFUSE = 1, USE_GLOSSY = 2, USE_GGX_REFL = 4, USE_GGX_REFR = 8, USE_DELTA = 16, USE_ALL = 31 };
 

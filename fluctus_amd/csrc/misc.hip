@@ -6,7 +6,9 @@
 
 namespace flxd {
 
+#ifndef MISC_BLOCK
 #define MISC_BLOCK 256
+#endif
 
 // Everything a (re)generated path starts from (src/wf_reset.cl:30-60 == src/wf_raygen.cl:77-96)
 __device__ __forceinline__ void init_path_state(const State &st, uint32_t gid, float shadowLen)
