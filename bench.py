@@ -7,13 +7,13 @@
 Workload (BASELINE.json configs[1]): the kitchen-class scene at 1920x1080, 8 bounces, env-map MIS, separate
 material queues.  Country-Kitchen.obj is a missing blob in the reference checkout, so the scene is the
 deterministic procedural stand-in "kitchen-proc" (~0.5 M triangles, the real .mtl's material-type mix,
-SURVEY 8(d)) with a synthetic HDR sky; SBVH built by the host library.  NUM_TASKS = 1 048 576 paths per
-GPU (reference default, src/settings.cpp:20).
+SURVEY 8(d)) with a synthetic HDR sky; SBVH built by the host library.  NUM_TASKS = 4 194 304 paths in flight per
+GPU (the reference's `wfBufferSize` setting, re-tuned for this chip -- see the comment at NUM_TASKS).
 
 A step = one benchmark-style iteration of the reference's runBenchmark body (src/tracer.cpp:433-439):
 logic -> raygen -> materials -> extension rays -> shadow rays -> end of iteration.
 Metric: Mrays/s = (sum of extension-queue lengths + sum of shadow-queue lengths) / time.
-Multi-GPU: every rank renders its own interleaved pixel subset with its own 1 M paths (weak scaling, no
+Multi-GPU: every rank renders its own interleaved pixel subset with its own NUM_TASKS paths (weak scaling, no
 collective in the timed region); the radiance tiles are gathered over RCCL afterwards (timed separately).
 """
 import argparse
@@ -28,7 +28,12 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 WIDTH, HEIGHT, BOUNCES = 1920, 1080, 8
-NUM_TASKS = 1 << 20
+# Paths in flight per GPU.  The reference's knob is the `wfBufferSize` setting (src/settings.cpp:20 "appropriate for dedicated GPU",
+# 1e6 in settings_default.json, i.e. sized for a GTX-class part); an MI355X holds 458 k lanes at once, so 1 M paths is only 2.3 per
+# lane and the traversal kernels spend much of their time in the tail.  Measured on kitchen-proc 1080p: 1 M 2762, 2 M 3027,
+# 4 M 3188, 8 M 3117-3212 Mrays/s (roofline.frac 0.61 / 0.74 / 0.81 / 0.86); beyond 4 M the path state (204 B/path) no longer fits
+# the 256 MB Infinity Cache and the cheaper scenes lose (conference: 3325 at 1 M, 3121 at 8 M).
+NUM_TASKS = 1 << 22
 TARGET_TRIS, SCENE_SEED = 500000, 42
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -268,7 +273,7 @@ def main():
     # visit counts come from an UNTIMED pass of the counting kernel variants over the same steady state
     ctx.trace_stats_enable(True)
     ctx.reset_stats()
-    for _ in range(8):
+    for _ in range(4):
         step_async(ctx)
     ctx.finish()
     st = ctx.stats()
