@@ -303,7 +303,9 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("extend_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))          # PMC capture of one configuration: only quoted for that configuration
+            if tj.get("num_tasks") == args.num_tasks // C and tj.get("workload") == args.workload:
+                traffic = tj.get("extend_hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
