@@ -129,6 +129,40 @@ def build_bvh(d, mode="sbvh"):
     return d
 
 
+def bvh_export(d, path, mode="sbvh"):
+    """Build and write the hierarchy cache file (the reference's on-disk format, host/bvh.hpp)."""
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_bvh_build(_p(d.tris), C.c_uint64(d.tris.size), BVH_MODES[mode], C.byref(h)))
+    try:
+        _chk(L.fh_bvh_export(h, path.encode()))
+    finally:
+        L.fh_bvh_destroy(h)
+
+
+def bvh_import(path):
+    """(nodes, indices) read back from a hierarchy cache file."""
+    L = lib()
+    h = C.c_void_p()
+    _chk(L.fh_bvh_import(path.encode(), C.byref(h)))
+    try:
+        nn, ni = C.c_uint64(), C.c_uint64()
+        met = (C.c_uint32 * 4)()
+        _chk(L.fh_bvh_counts(h, C.byref(nn), C.byref(ni), met))
+        nodes, idx = np.zeros(nn.value, NODE), np.zeros(ni.value, np.uint32)
+        _chk(L.fh_bvh_get(h, _p(nodes), _p(idx), None))
+        return nodes, idx
+    finally:
+        L.fh_bvh_destroy(h)
+
+
+def xxh64(data, seed=0):
+    L = lib()
+    L.fh_xxh64.restype = C.c_uint64
+    buf = np.frombuffer(bytes(data), np.uint8)
+    return int(L.fh_xxh64(buf.ctypes.data_as(C.c_void_p) if buf.size else None, C.c_uint64(buf.size), C.c_uint64(seed)))
+
+
 class EnvMap:
     def __init__(self, w, h, rgb, prob, alias, pdf):
         self.w, self.h, self.rgb, self.prob, self.alias, self.pdf = w, h, rgb, prob, alias, pdf

@@ -365,24 +365,88 @@ void BVH::exportTo(const std::string &filename) const
 {
     std::ofstream out(filename, std::ios::binary);
     if (!out) return;
-    const char magic[8] = {'F', 'L', 'X', 'B', 'V', 'H', '1', 0};
-    uint64_t ni = m_indices.size(), nn = m_nodes.size();
-    out.write(magic, 8); out.write((const char *)&ni, 8); out.write((const char *)&nn, 8);
-    out.write((const char *)m_indices.data(), ni * sizeof(uint32_t));
-    out.write((const char *)m_nodes.data(), nn * sizeof(flx_node));
+    const uint32_t ni = (uint32_t)m_indices.size(), nn = (uint32_t)m_nodes.size();
+    out.write((const char *)&ni, 4);
+    out.write((const char *)m_indices.data(), (std::streamsize)ni * 4);
+    out.write((const char *)&nn, 4);
+    std::vector<unsigned char> buf((size_t)nn * 33);
+    for (uint32_t i = 0; i < nn; i++) {
+        const flx_node &n = m_nodes[i];
+        unsigned char *p = &buf[(size_t)i * 33];
+        const float box[6] = {n.bmin.x, n.bmin.y, n.bmin.z, n.bmax.x, n.bmax.y, n.bmax.z};
+        std::memcpy(p, box, 24); std::memcpy(p + 24, &n.iStartOrRight, 4); std::memcpy(p + 28, &n.parent, 4); p[32] = n.nPrims;
+    }
+    out.write((const char *)buf.data(), (std::streamsize)buf.size());
 }
 
 bool BVH::importFrom(const std::string &filename)
 {
-    std::ifstream in(filename, std::ios::binary);
+    std::ifstream in(filename, std::ios::binary | std::ios::ate);
     if (!in) return false;
-    char magic[8]; uint64_t ni = 0, nn = 0;
-    in.read(magic, 8); in.read((char *)&ni, 8); in.read((char *)&nn, 8);
-    if (!in || std::memcmp(magic, "FLXBVH1", 7) != 0) return false;
-    m_indices.resize(ni); m_nodes.resize(nn);
-    in.read((char *)m_indices.data(), ni * sizeof(uint32_t));
-    in.read((char *)m_nodes.data(), nn * sizeof(flx_node));
-    return (bool)in;
+    const std::streamoff size = in.tellg();
+    in.seekg(0);
+    uint32_t ni = 0, header = 0;
+    in.read((char *)&ni, 4);
+    if (!in || (std::streamoff)(8 + (std::streamoff)ni * 4) > size) return false;
+    m_indices.resize(ni);
+    in.read((char *)m_indices.data(), (std::streamsize)ni * 4);
+    in.read((char *)&header, 4);
+    if (!in) return false;
+    const std::streamoff rest = size - (8 + (std::streamoff)ni * 4);
+    if (rest <= 0 || rest % 33 != 0) return false;
+    const size_t nn = (size_t)(rest / 33);                     // not `header`: see bvh.hpp
+    std::vector<unsigned char> buf(nn * 33);
+    in.read((char *)buf.data(), (std::streamsize)buf.size());
+    if (!in) return false;
+    m_nodes.assign(nn, flx_node());
+    for (size_t i = 0; i < nn; i++) {
+        const unsigned char *p = &buf[i * 33];
+        flx_node &n = m_nodes[i];
+        std::memset(&n, 0, sizeof(n));
+        float box[6]; std::memcpy(box, p, 24);
+        n.bmin.x = box[0]; n.bmin.y = box[1]; n.bmin.z = box[2]; n.bmax.x = box[3]; n.bmax.y = box[4]; n.bmax.z = box[5];
+        std::memcpy(&n.iStartOrRight, p + 24, 4); std::memcpy(&n.parent, p + 28, 4); n.nPrims = p[32];
+        // sanity: links must stay inside the arrays
+        if (n.nPrims == 0) { if (n.iStartOrRight >= nn || i + 1 >= nn) return false; }
+        else if ((size_t)n.iStartOrRight + n.nPrims > ni) return false;
+    }
+    return true;
+}
+
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t rd64(const unsigned char *p) { uint64_t v; std::memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const unsigned char *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+
+uint64_t xxh64(const void *data, size_t len, uint64_t seed)
+{
+    const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull, P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+    const unsigned char *p = (const unsigned char *)data, *end = p + len;
+    auto round = [&](uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; };
+    auto merge = [&](uint64_t h, uint64_t v) { v = round(0, v); h ^= v; return h * P1 + P4; };
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do { v1 = round(v1, rd64(p)); v2 = round(v2, rd64(p + 8)); v3 = round(v3, rd64(p + 16)); v4 = round(v4, rd64(p + 24)); p += 32; } while (p + 32 <= end);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else h = seed + P5;
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= round(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (*p) * P5; h = rotl64(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+uint64_t fileHash(const std::string &filename)
+{
+    std::ifstream f(filename, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("cannot open " + filename + " for hashing");
+    const std::streamoff n = f.tellg();
+    std::vector<char> data((size_t)n);
+    f.seekg(0);
+    if (n) f.read(data.data(), n);
+    return xxh64(data.data(), (size_t)n, 0);
 }
 
 } // namespace fluctus

@@ -39,8 +39,11 @@ public:
     BVH(const std::vector<flx_triangle> *tris, Mode mode) { build(tris, mode); }
     void build(const std::vector<flx_triangle> *tris, Mode mode);
 
-    // binary cache (reference: src/bvh.cpp:147-192; own format -- the reference writes the
-    // node count as m_indices.size(), src/bvh.cpp:185, which truncates trees; we store the real count)
+    // binary cache in the REFERENCE's on-disk format (src/bvh.cpp:102-192): u32 #indices, the indices, u32 count, then
+    // 33 bytes per node {bmin xyz, bmax xyz, u32 iStart/rightChild, i32 parent, u8 nPrims}.  The reference writes
+    // m_indices.size() into the node-count field (src/bvh.cpp:185) and reads that many nodes back, which truncates
+    // trees with more nodes than indices; here the field carries the true node count on export (so the reference loads
+    // our files in full) and import sizes the node array from the file length (so its files load in full here).
     void exportTo(const std::string &filename) const;
     bool importFrom(const std::string &filename);
 
@@ -54,5 +57,10 @@ public:
 private:
     const std::vector<flx_triangle> *m_tris = nullptr;
 };
+
+// XXH64 (Collet): the reference keys its caches by XXH64(scene file bytes, seed 0) printed in decimal
+// (src/utils.cpp:63-91, src/scene.cpp:46-51, src/tracer.cpp:576,640)
+uint64_t xxh64(const void *data, size_t len, uint64_t seed = 0);
+uint64_t fileHash(const std::string &filename);          // throws if the file cannot be read
 
 } // namespace fluctus

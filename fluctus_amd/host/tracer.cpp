@@ -2,6 +2,7 @@
 #include "tracer.hpp"
 #include <chrono>
 #include <sstream>
+#include <fstream>
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -50,15 +51,7 @@ void Tracer::initAreaLight()
     paramsUpdatePending = true;
 }
 
-static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 1469598103934665603ull)
-{
-    const unsigned char *p = (const unsigned char *)data;
-    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
-    return h;
-}
-
-// reference: src/tracer.cpp:574-590 -- cached hierarchy if present, else SBVH (always SplitMode::SAH -> SBVH) + export.
-// The cache key hashes the triangle positions instead of the file bytes (procedural scenes have no file).
+// reference: src/tracer.cpp:573-590 -- cached hierarchy if present, else SBVH (always SplitMode::SAH -> SBVH) + export
 void Tracer::initHierarchy()
 {
     delete bvh; bvh = new BVH();
@@ -66,8 +59,7 @@ void Tracer::initHierarchy()
     params.n_tris = (uint32_t)tris.size();
     std::string cache;
     if (!hierarchyCacheDir.empty()) {
-        std::ostringstream ss; ss << hierarchyCacheDir << "/hierarchy_" << fnv1a(tris.data(), tris.size() * sizeof(flx_triangle)) << ".bin";
-        cache = ss.str();
+        cache = hierarchyCacheDir + "/hierarchy_" + sceneHash + ".bin";
         if (bvh->importFrom(cache)) return;
     }
     bvh->build(&tris, BVH::Mode::SBVH);
@@ -87,7 +79,11 @@ void Tracer::init(int width, int height, const std::string &sceneFile)
         if (std::getline(ss, tok, ':')) tris = (uint32_t)std::stoul(tok);
         if (std::getline(ss, tok, ':')) seed = (uint32_t)std::stoul(tok);
         scene->generate(kind, tris, seed);
-    } else scene->loadModel(sceneFile);
+        sceneHash = std::to_string(xxh64(scene->getTriangles().data(), scene->getTriangles().size() * sizeof(flx_triangle)));   // no file to hash
+    } else {
+        scene->loadModel(sceneFile);
+        sceneHash = std::to_string(fileHash(sceneFile));                 // Scene::hashString (src/scene.cpp:46-51, 95)
+    }
     initHierarchy();
     params.worldRadius = bvh->worldRadius();                 // :66-67
     clctx->uploadSceneData(bvh, scene.get());
@@ -102,6 +98,44 @@ void Tracer::setEnvMap(const std::string &hdrFile)
     clctx->createEnvMap(envMap.get());
     params.useEnvMap = 1;
     paramsUpdatePending = true;
+}
+
+// reference: src/tracer.cpp:625-684 (iterateStateItems): one item after the other in native byte order
+namespace {
+struct StateIO {
+    std::fstream f; bool write;
+    template <class T> void rw(T &v) { if (write) f.write((const char *)&v, sizeof(T)); else f.read((char *)&v, sizeof(T)); }
+    void vec(flx_vec3 &v) { rw(v.x); rw(v.y); rw(v.z); }
+};
+}
+static bool stateItems(const std::string &path, bool write, RenderParams &p, float *cameraRotation, float &cameraSpeed)
+{
+    StateIO io; io.write = write;
+    io.f.open(path, std::ios::binary | (write ? std::ios::out : std::ios::in));
+    if (!io.f.good()) return false;
+    io.rw(cameraRotation[0]); io.rw(cameraRotation[1]); io.rw(cameraSpeed);
+    io.rw(p.camera.fov); io.rw(p.camera.focalDist); io.rw(p.camera.apertureSize);
+    io.vec(p.camera.dir); io.vec(p.camera.pos); io.vec(p.camera.right); io.vec(p.camera.up);
+    io.vec(p.areaLight.N); io.vec(p.areaLight.pos); io.vec(p.areaLight.right); io.vec(p.areaLight.up); io.vec(p.areaLight.E);
+    io.rw(p.areaLight.size.x); io.rw(p.areaLight.size.y); io.rw(p.envMapStrength);
+    io.rw(p.maxBounces); io.rw(p.useAreaLight); io.rw(p.useEnvMap); io.rw(p.sampleExpl); io.rw(p.sampleImpl); io.rw(p.useRoulette);
+    io.rw(p.exposure); io.rw(p.tmOperator);
+    return io.f.good();
+}
+bool Tracer::saveState() const
+{
+    if (stateDir.empty()) return false;
+    RenderParams p = params; float rot[2] = {cameraRotation[0], cameraRotation[1]}; float speed = cameraSpeed;
+    return stateItems(stateDir + "/state_" + sceneHash + ".dat", true, p, rot, speed);
+}
+bool Tracer::loadState()
+{
+    if (stateDir.empty()) return false;
+    RenderParams p = params; float rot[2] = {0.0f, 0.0f}; float speed = 1.0f;
+    if (!stateItems(stateDir + "/state_" + sceneHash + ".dat", false, p, rot, speed)) return false;
+    params = p; cameraRotation[0] = rot[0]; cameraRotation[1] = rot[1]; cameraSpeed = speed;
+    paramsUpdatePending = true;
+    return true;
 }
 
 // reference: src/tracer.cpp:95-187

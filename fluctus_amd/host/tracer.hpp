@@ -37,7 +37,15 @@ public:
     Scene *getScene() { return scene.get(); }
     uint32_t getIteration() const { return iteration; }
     const QueueCounters &lastCounters() const { return lastCnt; }
-    std::string hierarchyCacheDir = "";                                           // empty = no on-disk BVH cache
+    // on-disk caches in the reference's formats and names (src/tracer.cpp:573-590, 625-684): <dir>/hierarchy_<hash>.bin and
+    // <dir>/state_<hash>.dat, hash = XXH64 of the scene file in decimal (of the triangle array for procedural scenes)
+    std::string hierarchyCacheDir = "";                                           // empty = no on-disk BVH cache ("data/hierarchies" in the reference)
+    std::string stateDir = "";                                                    // "data/states" in the reference
+    bool saveState() const;                                                       // Tracer::saveState: camera, lights, sampling and post-processing parameters
+    bool loadState();                                                             // false when there is no (complete) state file for this scene
+    const std::string &getSceneHash() const { return sceneHash; }
+    float cameraRotation[2] = {0.0f, 0.0f};                                       // UI state the file carries (src/tracer.hpp: cameraRotation, cameraSpeed)
+    float cameraSpeed = 1.0f;
 
 private:
     void resetParams(int width, int height);
@@ -58,6 +66,7 @@ private:
     bool useWavefront = true;                                                     // this library's default; the reference starts on MK (src/tracer.cpp:11)
     QueueCounters lastCnt {};
     std::string sceneName;
+    std::string sceneHash;
 };
 
 } // namespace fluctus

@@ -65,6 +65,22 @@ class Tracer:
         host._chk(self.L.fh_tracer_stats(self.h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def set_cache_dirs(self, hierarchies="", states=""):
+        """Directories of the reference-format caches: hierarchy_<hash>.bin (BVH) and state_<hash>.dat (camera/light/sampling state)."""
+        self.L.fh_tracer_set_cache_dirs(self.h, hierarchies.encode(), states.encode())
+
+    def save_state(self):
+        return self.L.fh_tracer_save_state(self.h) == 0
+
+    def load_state(self):
+        return self.L.fh_tracer_load_state(self.h) == 0
+
+    @property
+    def scene_hash(self):
+        buf = C.create_string_buffer(64)
+        host._chk(self.L.fh_tracer_scene_hash(self.h, buf, C.c_uint64(64)))
+        return buf.value.decode()
+
     def run_benchmark(self, seconds=1.0, iterations=0):
         buf = C.create_string_buffer(1 << 20)
         host._chk(self.L.fh_tracer_run_benchmark(self.h, C.c_double(seconds), int(iterations), buf, C.c_uint64(len(buf))))

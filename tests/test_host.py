@@ -456,3 +456,43 @@ def test_pbrt_round_trip_of_a_procedural_scene(tmp_path, kind):
         if int(a["type"]) in (wire.BXDF.GLOSSY, wire.BXDF.GGX_ROUGH_REFLECTION, wire.BXDF.IDEAL_DIELECTRIC):
             assert np.isclose(a["Ni"], b["Ni"], rtol=1e-6)
     assert off == r.tris.size
+
+
+# ---------------------------------------------------------------- on-disk caches in the reference's formats
+def test_xxh64_matches_the_xxhash_library():
+    import xxhash
+    rng = np.random.RandomState(1)
+    for n in (0, 1, 3, 4, 7, 8, 15, 31, 32, 33, 63, 64, 100, 4097):
+        data = rng.randint(0, 256, n).astype(np.uint8).tobytes()
+        for seed in (0, 1, 2**63 + 5):
+            assert host.xxh64(data, seed) == xxhash.xxh64(data, seed=seed).intdigest(), (n, seed)
+
+
+@pytest.mark.parametrize("mode", ["sbvh", "sah"])
+def test_hierarchy_cache_file_is_the_reference_format(tmp_path, mode):
+    """src/bvh.cpp:102-192: u32 #indices, indices, u32 count, 33 bytes per node {6 floats, u32 iStart|rightChild, i32 parent, u8 nPrims}."""
+    d = host.generate_scene("conference", 3000, 1)
+    host.build_bvh(d, mode)
+    path = str(tmp_path / "hierarchy_1.bin")
+    host.bvh_export(d, path, mode)
+    raw = open(path, "rb").read()
+    ni = int(np.frombuffer(raw, "<u4", 1)[0])
+    assert ni == d.indices.size and np.array_equal(np.frombuffer(raw, "<u4", ni, 4), d.indices)
+    nn = int(np.frombuffer(raw, "<u4", 1, 4 + 4 * ni)[0])
+    assert nn == d.nodes.size and len(raw) == 8 + 4 * ni + 33 * nn
+    rec = np.frombuffer(raw, np.dtype([("box", "<f4", 6), ("istart", "<u4"), ("parent", "<i4"), ("nprims", "u1")]), nn, 8 + 4 * ni)
+    assert np.array_equal(rec["istart"], d.nodes["iStartOrRight"]) and np.array_equal(rec["parent"], d.nodes["parent"]) and np.array_equal(rec["nprims"], d.nodes["nPrims"])
+    assert np.array_equal(rec["box"][:, 0], d.nodes["bmin"]["x"]) and np.array_equal(rec["box"][:, 5], d.nodes["bmax"]["z"])
+    nodes, idx = host.bvh_import(path)
+    assert np.array_equal(idx, d.indices)
+    for f in ("parent", "iStartOrRight", "nPrims"):
+        assert np.array_equal(nodes[f], d.nodes[f])
+    assert np.array_equal(nodes["bmin"], d.nodes["bmin"]) and np.array_equal(nodes["bmax"], d.nodes["bmax"])
+    # a file as the REFERENCE writes it: the count field holds #indices (src/bvh.cpp:185); every node must still come back
+    bad = bytearray(raw); bad[4 + 4 * ni: 8 + 4 * ni] = np.uint32(ni).tobytes()
+    p2 = str(tmp_path / "ref.bin"); open(p2, "wb").write(bytes(bad))
+    nodes2, _ = host.bvh_import(p2)
+    assert nodes2.size == nn
+    open(p2, "wb").write(raw[:-5])                                    # truncated file: refused
+    with pytest.raises(RuntimeError):
+        host.bvh_import(p2)

@@ -98,3 +98,54 @@ def test_cpp_tracer_render_single_and_microkernel_update():
     assert t.uses_wavefront
     with pytest.raises(RuntimeError, match="numTasks"):
         t2 = Tracer(w, h, 0, 1000); t2.init(w, h, "proc:kitchen:2000:7"); t2.render_single(1)
+
+
+@pytest.mark.gpu
+def test_cpp_tracer_reference_format_caches(tmp_path):
+    """Tracer::initHierarchy / saveState / loadState with the reference's file names and layouts (src/tracer.cpp:573-590, 625-684):
+    <dir>/hierarchy_<XXH64 of the scene file>.bin and <dir>/state_<hash>.dat (44 four-byte items)."""
+    import xxhash
+    from fluctus_amd.tracer import Tracer
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv -1 1 -1\nv 1 1 -1\nv 1 2 1\nf 1 2 3\nf 1 3 4\nf 5 6 7\n")
+    hdir, sdir = tmp_path / "hierarchies", tmp_path / "states"
+    hdir.mkdir(); sdir.mkdir()
+    w, h = 48, 32
+    t = Tracer(w, h, 0, 4096)
+    t.set_cache_dirs(str(hdir), str(sdir))
+    t.init(w, h, str(obj))
+    want = str(xxhash.xxh64(obj.read_bytes(), seed=0).intdigest())
+    assert t.scene_hash == want
+    cache = hdir / f"hierarchy_{want}.bin"
+    assert cache.exists()
+    nodes, idx = host.bvh_import(str(cache))
+    assert idx.size >= 3 and nodes.size >= 1
+    p = t.params
+    wire.look_at(p, (0.0, 3.0, 4.0), (0.0, 0.5, 0.0))
+    p["maxBounces"], p["envMapStrength"], p["exposure"], p["tmOperator"], p["useRoulette"] = 5, 2.5, 1.75, 1, 1
+    t.params = p
+    for _ in range(4):
+        t.update()
+    img = t.read_pixels(0)
+    assert t.save_state()
+    sfile = sdir / f"state_{want}.dat"
+    assert sfile.stat().st_size == 44 * 4
+    raw = np.frombuffer(sfile.read_bytes(), "<f4")
+    assert np.isclose(raw[3], float(p["camera"]["fov"])) and np.allclose(raw[9:12], [p["camera"]["pos"][k] for k in "xyz"])   # after rotation(2), speed, fov, focalDist, aperture, dir(3)
+    # a second tracer picks up both caches: same hierarchy (same image), same parameters
+    t2 = Tracer(w, h, 0, 4096)
+    t2.set_cache_dirs(str(hdir), str(sdir))
+    t2.init(w, h, str(obj))
+    assert t2.load_state()
+    q = t2.params
+    for f in ("maxBounces", "envMapStrength", "exposure", "tmOperator", "useRoulette", "useAreaLight", "useEnvMap", "sampleExpl", "sampleImpl"):
+        assert q[f] == p[f], f
+    for f in ("pos", "dir", "up", "right"):
+        assert all(q["camera"][f][k] == p["camera"][f][k] for k in "xyz")
+    for _ in range(4):
+        t2.update()
+    assert np.array_equal(t2.read_pixels(0)[:, 3], img[:, 3]) and np.allclose(t2.read_pixels(0), img, rtol=1e-6, atol=1e-7)
+    t3 = Tracer(w, h, 0, 4096)
+    t3.set_cache_dirs(str(hdir), str(tmp_path / "nowhere"))
+    t3.init(w, h, str(obj))
+    assert not t3.load_state()
