@@ -26,7 +26,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for key in ("k_extend", "k_shadow", "k_trace_stream", "k_logic", "k_material<1>"):
+        for key in ("k_extend<false>", "k_shadow<false>", "k_trace_stream", "k_logic", "k_material<1>"):   # <false> = the product kernels, not the STATS counting variants
             if key in k:
                 a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(acc):
