@@ -54,7 +54,28 @@ def build_workload(width=None, height=None, name="kitchen"):
     width, height = width or w, height or h
     tris = int(os.environ.get("FLX_BENCH_TRIS", tris))          # experiments only (scripts/sweep.sh); the bench line uses the default
     d = host.generate_scene(gen, tris, seed)
-    host.build_bvh(d, bvh)
+    # hierarchy cache (the reference's on-disk format, host/bvh.hpp) so that the back-to-back N = 1, 2, 4, 8 runs and the N ranks of
+    # one run do not each spend 10-40 s in the SBVH builder; written atomically, keyed by the generator arguments
+    cache_dir = os.environ.get("FLX_BVH_CACHE", "/tmp/flx_bvh_cache")
+    cache = os.path.join(cache_dir, f"hierarchy_{gen}_{tris}_{seed}_{bvh}_{d.tris.size}.bin")
+    loaded = False
+    if cache_dir and os.path.exists(cache):
+        try:
+            d.nodes, d.indices = host.bvh_import(cache)
+            d.world_radius = host.bvh_import.world_radius
+            loaded = True
+        except Exception:
+            loaded = False
+    if not loaded:
+        host.build_bvh(d, bvh)
+        if cache_dir:
+            try:
+                os.makedirs(cache_dir, exist_ok=True)
+                tmp = f"{cache}.{os.getpid()}.tmp"
+                host.bvh_export_arrays(d, tmp)
+                os.replace(tmp, cache)
+            except Exception:
+                pass
     p = wire.default_params(width, height, d.world_radius, d.tris.size)
     wire.look_at(p, cam, target, fov=60.0)
     p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = bounces, use_env, use_area, 1

@@ -150,10 +150,24 @@ def bvh_import(path):
         met = (C.c_uint32 * 4)()
         _chk(L.fh_bvh_counts(h, C.byref(nn), C.byref(ni), met))
         nodes, idx = np.zeros(nn.value, NODE), np.zeros(ni.value, np.uint32)
-        _chk(L.fh_bvh_get(h, _p(nodes), _p(idx), None))
+        wr = C.c_float()
+        _chk(L.fh_bvh_get(h, _p(nodes), _p(idx), C.byref(wr)))
+        bvh_import.world_radius = wr.value           # of the last import (root box), same arithmetic as a fresh build
         return nodes, idx
     finally:
         L.fh_bvh_destroy(h)
+
+
+def bvh_export_arrays(d, path):
+    """Write d.nodes / d.indices as a hierarchy cache file without rebuilding (same bytes as BVH::exportTo)."""
+    rec = np.zeros(d.nodes.size, np.dtype([("box", "<f4", 6), ("istart", "<u4"), ("parent", "<i4"), ("nprims", "u1")]))
+    for k, ax in enumerate("xyz"):
+        rec["box"][:, k] = d.nodes["bmin"][ax]
+        rec["box"][:, 3 + k] = d.nodes["bmax"][ax]
+    rec["istart"], rec["parent"], rec["nprims"] = d.nodes["iStartOrRight"], d.nodes["parent"], d.nodes["nPrims"]
+    with open(path, "wb") as f:
+        f.write(np.uint32(d.indices.size).tobytes()); f.write(np.ascontiguousarray(d.indices, "<u4").tobytes())
+        f.write(np.uint32(d.nodes.size).tobytes()); f.write(rec.tobytes())
 
 
 def xxh64(data, seed=0):

@@ -496,3 +496,16 @@ def test_hierarchy_cache_file_is_the_reference_format(tmp_path, mode):
     open(p2, "wb").write(raw[:-5])                                    # truncated file: refused
     with pytest.raises(RuntimeError):
         host.bvh_import(p2)
+
+
+def test_bench_workload_hierarchy_cache_is_transparent(tmp_path, monkeypatch):
+    """bench.py caches the hierarchy of its procedural scenes in the reference's file format: a cached run must hand the device
+    exactly the arrays and parameters a fresh build does."""
+    import bench
+    monkeypatch.setenv("FLX_BVH_CACHE", str(tmp_path))
+    monkeypatch.setenv("FLX_BENCH_TRIS", "20000")
+    d1, p1, _ = bench.build_workload(name="kitchen")
+    assert len(list(tmp_path.iterdir())) == 1
+    d2, p2, _ = bench.build_workload(name="kitchen")
+    assert np.array_equal(d1.nodes, d2.nodes) and np.array_equal(d1.indices, d2.indices)
+    assert d1.world_radius == d2.world_radius and np.array_equal(p1, p2)
