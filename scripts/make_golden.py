@@ -8,6 +8,7 @@ reference kernels produced for them.  No reference source is stored.
                   16384 paths): per-iteration queue counters and the accumulated image after 24 iterations.
   steps_*.npz     all-BSDF scene: path state / queues / counters after every kernel of two consecutive
                   iterations (state k -> kernel -> state k+1 chains), for two flag sets.
+  steps_denoiser_* the same with the reference's USE_OPTIX_DENOISER kernel builds: + the feature accumulators after every kernel.
   raygen.npz      genRays outputs (seed stream, pixel index, ray origin/direction) for 4096 paths.
 """
 import os
@@ -30,9 +31,12 @@ def scene_arrays(d):
                 materials=d.materials.view(np.uint8).reshape(-1), texdesc=d.texdesc.view(np.uint8).reshape(-1), texdata=d.texdata)
 
 
-def snapshot(c):
+def snapshot(c, aov=False):
     cnt = c.get_counters().copy()
-    return dict(state=c.state_export(), counters=cnt, queues=np.stack([c.queue_read(q) for q in range(8)]))
+    s = dict(state=c.state_export(), counters=cnt, queues=np.stack([c.queue_read(q) for q in range(8)]))
+    if aov:
+        s["aov"] = np.stack([c.read_pixels(4), c.read_pixels(5)])          # denoiser feature accumulators: albedo, normal
+    return s
 
 
 def teapot():
@@ -50,25 +54,30 @@ def teapot():
     print("teapot_wf.npz", cnts[-1])
 
 
-def steps(tag, **flags):
+def steps(tag, denoiser=False, **flags):
     d = common.mixed_material_scene()
     w, h, n = 48, 32, 1024
     p = common.scene_params(d, w, h, maxBounces=5, envMapStrength=1.5, **flags)
     e = host.synthetic_sky(64, 32)
     c = RefContext(n)
+    if denoiser:
+        c.set_option("denoiser", 1)                                         # the -DUSE_OPTIX_DENOISER builds of logic / process
     c.upload_scene(d); c.upload_envmap(e); c.set_params(p); driver.reset_renderer(c)
     for _ in range(6):
         driver.benchmark_iteration(c, w * h)
-    snaps, names = [snapshot(c)], ["start"]
+    _snap = snapshot
+    snapshot_ = lambda ctx: _snap(ctx, aov=denoiser)
+    snaps, names = [snapshot_(c)], ["start"]
     for it in range(2):
         for name, fn in (("logic", lambda: c.wf_logic(False)), ("raygen", c.wf_raygen), ("materials", c.wf_materials),
                          ("extend", c.wf_extend), ("shadow", c.wf_shadow)):
             fn()
-            snaps.append(snapshot(c)); names.append(name)
+            snaps.append(snapshot_(c)); names.append(name)
         cnt = c.get_counters().copy()
         c.clear_queues(); c.pixel_index_update(w * h, int(cnt[0]))
-        snaps.append(snapshot(c)); names.append("end")
-    np.savez_compressed(os.path.join(OUT, f"steps_{tag}.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8),
+        snaps.append(snapshot_(c)); names.append("end")
+    extra = dict(aov=np.stack([s["aov"] for s in snaps])) if denoiser else {}
+    np.savez_compressed(os.path.join(OUT, f"steps_{tag}.npz"), num_tasks=n, **extra, params=np.asarray(p).reshape(1).view(np.uint8),
                         names=np.array(names), states=np.stack([s["state"] for s in snaps]),
                         counters=np.stack([s["counters"] for s in snaps]), queues=np.stack([s["queues"] for s in snaps]),
                         env_rgb=e.rgb, env_prob=e.prob, env_alias=e.alias, env_pdf=e.pdf, env_wh=np.array([e.w, e.h]),
@@ -110,6 +119,7 @@ if __name__ == "__main__":
     teapot()
     steps("area_sep", useAreaLight=1, useEnvMap=0, wfSeparateQueues=1)
     steps("env_area_single_rr", useAreaLight=1, useEnvMap=1, wfSeparateQueues=0, useRoulette=1)
+    steps("denoiser_env_area_sep", denoiser=True, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)
     raygen()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -307,7 +307,7 @@ def test_single_leaf_scene_and_deep_stack_spill():
     _free_run(g, o, 32 * 32, 6)
 
 
-@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr"])
+@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr", "denoiser_env_area_sep"])
 def test_device_vs_reference_kernel_outputs(tag):
     """The HIP path directly against the REFERENCE kernels' own outputs (tests/golden/steps_*.npz, produced by
     oracle/_ref): every kernel of two iterations, from the reference's input state.  Integers exact, floats within the
@@ -327,7 +327,12 @@ def test_device_vs_reference_kernel_outputs(tag):
     e = host.EnvMap(int(z["env_wh"][0]), int(z["env_wh"][1]), z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])
     g = HipContext(n)
     g.set_option("trace_mode", TRACE_MODE["mode"])
+    den = "aov" in z.files                         # fixture made with the reference's USE_OPTIX_DENOISER kernel builds
+    if den:
+        g.set_option("denoiser", 1)
     g.upload_scene(d); g.upload_envmap(e); g.set_params(p)
+    if den:
+        g.wf_reset()                               # feature buffers to their reset values
     names = [str(s) for s in z["names"]]
     fn = {"logic": lambda: g.wf_logic(False), "materials": g.wf_materials, "extend": g.wf_extend, "shadow": g.wf_shadow}
     for k in range(1, len(names)):
@@ -337,8 +342,16 @@ def test_device_vs_reference_kernel_outputs(tag):
         for q in range(8):
             g.queue_write(q, z["queues"][k - 1][q])
         g.set_counters(z["counters"][k - 1])
+        if den:
+            before = np.stack([g.read_pixels(4), g.read_pixels(5)])
         fn[names[k]]()
         cnt = g.get_counters(); g.finish()
+        if den:                                    # what this kernel ADDED to the albedo / normal accumulators vs what the reference's added
+            after = np.stack([g.read_pixels(4), g.read_pixels(5)])
+            want = z["aov"][k] - z["aov"][k - 1]
+            assert np.array_equal((after - before)[..., 3], want[..., 3]), (names[k], "feature counts")
+            assert np.allclose(after - before, want, rtol=1e-4, atol=1e-4), (names[k], "feature sums")
+            assert names[k] == "logic" or not want.any()
         assert np.array_equal(cnt, z["counters"][k]), (k, names[k])
         for q in range(8):
             m = int(z["counters"][k][q])

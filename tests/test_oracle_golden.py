@@ -43,7 +43,7 @@ def test_raygen_golden():
     assert not fails, "; ".join(fails)
 
 
-@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr"])
+@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr", "denoiser_env_area_sep"])
 def test_kernel_steps_golden(tag):
     """G3/G4/G6: every kernel of two iterations, all six BSDFs, textures, env-map MIS: oracle output from the
     reference's input state vs the reference's output state."""
@@ -54,7 +54,12 @@ def test_kernel_steps_golden(tag):
     w, h = int(z["env_wh"][0]), int(z["env_wh"][1])
     e = host.EnvMap(w, h, z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])
     c = OracleContext(n)
+    den = "aov" in z.files                          # made with the reference's USE_OPTIX_DENOISER kernel builds
+    if den:
+        c.set_option("denoiser", 1)
     c.upload_scene(d); c.upload_envmap(e); c.set_params(p)
+    if den:
+        c.wf_reset()
     names = [str(s) for s in z["names"]]
     npix = int(p["width"]) * int(p["height"])
     # the fixture starts after 6 free-running reference iterations; replay the cursor from the counters
@@ -70,7 +75,13 @@ def test_kernel_steps_golden(tag):
         c.set_counters(z["counters"][prev])
         if names[k] == "raygen":
             continue            # needs the reference's pixel cursor; covered by test_raygen_golden and the e2e fixture
+        if den:
+            before = np.stack([c.read_pixels(4), c.read_pixels(5)])
         fn[names[k]]()
+        if den:                                     # the kernel's contribution to the denoiser feature accumulators
+            want = z["aov"][k] - z["aov"][k - 1]
+            got = np.stack([c.read_pixels(4), c.read_pixels(5)]) - before
+            assert np.array_equal(got[..., 3], want[..., 3]) and np.allclose(got, want, rtol=1e-4, atol=1e-4), names[k]
         assert np.array_equal(c.get_counters(), z["counters"][k]), (k, names[k])
         for q in range(8):
             m = int(z["counters"][k][q])
