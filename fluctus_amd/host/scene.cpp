@@ -179,9 +179,9 @@ std::vector<MtlEntry> readMtl(const std::string &path)
 } // namespace
 
 // reference: scene.cpp:191-301.  matId = mtl index + 1 (0 = default material); flat normal when
-// any vertex normal is missing; texcoord zero when absent.  Texture images are not decoded here
-// (DevIL is not available) -- map_* stay -1 unless a texture was registered
-// under the same name with addTexture() before loading.
+// any vertex normal is missing; texcoord zero when absent.  map_Kd / map_Ks / map_bump images are decoded by
+// tryImportTexture (PNG, JPEG; texture.cpp, jpeg.cpp); a missing or undecodable file leaves the slot at -1, and a texture
+// registered under the same name with addTexture() beforehand is reused.
 void Scene::loadObjWithMaterials(const std::string &filePath)
 {
     std::ifstream in(filePath);
