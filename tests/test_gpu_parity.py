@@ -193,12 +193,16 @@ def test_large_queue_properties():
     assert (st[COL.PATH_LEN] <= int(p["maxBounces"]) + 1).all()
 
 
-def test_full_size_kitchen_properties_and_determinism():
-    """BASELINE.json configs[1] at full size (kitchen-proc ~0.5 M triangles, 1920x1080, 8 bounces, env-map MIS, 1 M paths):
-    too big for the oracle, so size-independent properties are checked, and two independent runs must agree bit for bit."""
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
+def test_full_size_properties_and_determinism(workload):
+    """BASELINE.json configs[1..3] at full size (kitchen-proc ~0.5 M triangles 1920x1080 8 bounces env-map MIS; conference-proc
+    GGX + area light; courtyard-proc 8.9 M triangles 2560x1440 12 bounces, all BSDFs), 1 M paths: too big for the oracle, so
+    size-independent properties are checked, and two independent runs -- different stream schedules -- must agree bit for bit."""
     from fluctus_amd.device import HipContext
     import bench
-    d, p, env = bench.build_workload()
+    if workload != "kitchen" and (TRACE_MODE["mode"] != 0 or TRACE_MODE["xcd"] or TRACE_MODE["overlap"] != 2):
+        pytest.skip("the A/B kernel variants are exercised at full size on the kitchen scene only")
+    d, p, env = bench.build_workload(name=workload)
     n, npix = 1 << 20, int(p["width"]) * int(p["height"])
     outs = []
     for run in range(2):
