@@ -344,8 +344,14 @@ def main():
         full = multi.gather_tiles(tile, args.width * args.height, rank, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        gather_ok = None
         if rank == 0:
             assert torch.isfinite(full).all() and lp > 0
+            # the gathered image holds rank r's tile at global pixels r, r + world, ...: rank 0's slice must be what
+            # flx_read_pixels returns for its own framebuffer (bit for bit: nothing rendered in between)
+            own = ctxs[0].read_pixels(0)
+            gather_ok = bool(np.array_equal(full[0::world][:lp].cpu().numpy(), own))
+            assert gather_ok, "gathered image differs from flx_read_pixels"
 
     if rank == 0:
         line = {
@@ -379,6 +385,7 @@ def main():
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
+            line["gather_matches_read_pixels"] = gather_ok
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
             if line["cpu_baseline"]["kind"] == "reference":      # the oracle port beside it (order-preserving appends instead of per-path atomics)

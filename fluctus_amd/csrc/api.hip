@@ -431,7 +431,11 @@ uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
 int flx_wf_reset(flx_ctx *c) { READY(c); flushExt(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
-int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } c->qs.extPend |= 1u << FLX_Q_RAYGEN; if (c->eagerBump) flushExt(c); LAUNCHED(c); return 0; }
+// Appending a source queue a second time before the pending lengths were folded into the counter would compute slots from
+// a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
+// call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
+static void flushExtIfPending(flx_ctx *c, uint32_t bits) { if (c->qs.extPend & bits) flushExt(c); }
+int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); flushExtIfPending(c, 1u << FLX_Q_RAYGEN); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } c->qs.extPend |= 1u << FLX_Q_RAYGEN; if (c->eagerBump) flushExt(c); LAUNCHED(c); return 0; }
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
@@ -494,19 +498,24 @@ int flx_wf_logic(flx_ctx *c, int first)
     if (c->overlap == 2) { HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream)); c->logicChain = true; }
     return 0;
 }
-int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c); { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); }
-    c->qs.extPend |= c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
+int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c);
+    const uint32_t bits = c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
+    flushExtIfPending(c, bits);
+    { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); }
+    c->qs.extPend |= bits;
     if (c->eagerBump) flushExt(c);
     LAUNCHED(c); return 0; }
 int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
-// ---- microkernel integrator
-int flx_mk_reset(flx_ctx *c) { READY(c); launch_mk_reset(c->stream, c->st, c->fr, c->params); LAUNCHED(c); return 0; }
-int flx_mk_raygen(flx_ctx *c) { READY(c); launch_mk_raygen(c->stream, c->st, c->params); LAUNCHED(c); return 0; }
-int flx_mk_next_vertex(flx_ctx *c) { READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
-int flx_mk_sample_bsdf(flx_ctx *c) { READY(c); launch_mk_sample_bsdf(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
-int flx_mk_splat(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 0); LAUNCHED(c); return 0; }
-int flx_mk_splat_preview(flx_ctx *c) { READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
+// ---- microkernel integrator.  One path per pixel, framebuffers indexed by the path id: single-GPU only, the pixel
+// partition belongs to the wavefront path (allocFrame sizes the buffers for the rank's LOCAL pixels).
+#define MK_READY(c) do { READY(c); NEED(c, (c)->fr.nranks == 1, "the microkernel integrator is single-GPU: flx_set_partition(ctx, 0, 1) first"); } while (0)
+int flx_mk_reset(flx_ctx *c) { MK_READY(c); launch_mk_reset(c->stream, c->st, c->fr, c->params); LAUNCHED(c); return 0; }
+int flx_mk_raygen(flx_ctx *c) { MK_READY(c); launch_mk_raygen(c->stream, c->st, c->params); LAUNCHED(c); return 0; }
+int flx_mk_next_vertex(flx_ctx *c) { MK_READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_sample_bsdf(flx_ctx *c) { MK_READY(c); launch_mk_sample_bsdf(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
+int flx_mk_splat(flx_ctx *c) { MK_READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 0); LAUNCHED(c); return 0; }
+int flx_mk_splat_preview(flx_ctx *c) { MK_READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
 int flx_mk_stats_async(flx_ctx *c, void *out16)
 {
     MUTATES(c);

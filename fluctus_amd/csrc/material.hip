@@ -9,7 +9,8 @@
 // (the reference gets the same effect from -DBXDF_USE_* at OpenCL build time).  For every queued
 // path: evaluate f and pdf toward the stored light direction (consumed by `logic` next iteration),
 // sample the continuation direction, update throughput, write the new ray and append the path to
-// the extension queue with a wave-aggregated atomic.
+// the extension queue at a COMPUTED slot (extension base + lengths of the source queues appended earlier
+// + own index; no atomic -- see flx_device.h).
 #include "flx_bsdf.h"
 
 namespace flxd {

@@ -193,10 +193,10 @@ def test_large_queue_properties():
     assert (st[COL.PATH_LEN] <= int(p["maxBounces"]) + 1).all()
 
 
-@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p", "courtyard-2160p"])
 def test_full_size_properties_and_determinism(workload):
-    """BASELINE.json configs[1..3] at full size (kitchen-proc ~0.5 M triangles 1920x1080 8 bounces env-map MIS; conference-proc
-    GGX + area light; courtyard-proc 8.9 M triangles 2560x1440 12 bounces, all BSDFs), 1 M paths: too big for the oracle, so
+    """BASELINE.json configs[1..4] at full size (kitchen-proc ~0.5 M triangles 1920x1080 8 bounces env-map MIS; conference-proc
+    GGX + area light; courtyard-proc 8.9 M triangles 2560x1440 12 bounces and 3840x2160 16 bounces, all BSDFs), 1 M paths: too big for the oracle, so
     size-independent properties are checked, and two independent runs -- different stream schedules -- must agree bit for bit."""
     from fluctus_amd.device import HipContext
     import bench
