@@ -198,8 +198,22 @@ FLX_HD f3 cross(f3 a, f3 b)
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 FLX_HD float length(f3 a) { return sqrtf(dot(a, a)); }
-/* normalize: one correctly rounded reciprocal of the length, then 3 multiplies */
-FLX_HD f3 normalize(f3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+/* normalize: one correctly rounded reciprocal of the length, then 3 multiplies.  Edge cases as OpenCL 1.2 s7.5.1 defines them for the
+ * built-in the reference calls (and as ROCm's OpenCL on the MI355X returns them, profiles/r02_ocl_builtin_gap.json): a vector of zeros is
+ * returned unchanged (NOT 0 * inf = NaN -- the stale all-zero shadowDir of a path without NEE reaches bxdfEval this way,
+ * src/wf_mat_diffuse.cl:34-37); an infinite element counts as +-1 and every finite one as 0; NaN stays NaN. */
+FLX_HD f3 normalize(f3 a)
+{
+    if (a.x == 0.0f && a.y == 0.0f && a.z == 0.0f) return a;
+    const float big = FLX_FLT_MAX;
+    if (absf(a.x) > big || absf(a.y) > big || absf(a.z) > big) {
+        a.x = absf(a.x) > big ? __builtin_copysignf(1.0f, a.x) : 0.0f * a.x;
+        a.y = absf(a.y) > big ? __builtin_copysignf(1.0f, a.y) : 0.0f * a.y;
+        a.z = absf(a.z) > big ? __builtin_copysignf(1.0f, a.z) : 0.0f * a.z;
+    }
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return a * inv;
+}
 FLX_HD bool is_zero(f3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 FLX_HD f3 pow3(f3 v, float e) { return mk3(powf_(v.x, e), powf_(v.y, e), powf_(v.z, e)); }
 FLX_HD f3 min3(f3 a, f3 b) { return mk3(fminf_(a.x, b.x), fminf_(a.y, b.y), fminf_(a.z, b.z)); }

@@ -68,7 +68,17 @@ float b_fmin(float a, float b) __asm__("_Z4fminff"); float b_fmin(float a, float
 float b_fmax(float a, float b) __asm__("_Z4fmaxff"); float b_fmax(float a, float b) { return fmaxf(a, b); }
 float b_native_sin(float x) __asm__("_Z10native_sinf"); float b_native_sin(float x) { return sinf(x); }
 float b_native_cos(float x) __asm__("_Z10native_cosf"); float b_native_cos(float x) { return cosf(x); }
-float b_native_powr(float x, float y) __asm__("_Z11native_powrff"); float b_native_powr(float x, float y) { return powf(x, y); }
+/* powr(x, y): x >= 0 by definition; OpenCL 1.2 s7.5.1: powr(x < 0, y), powr(+-0, +-0), powr(+inf, +-0), powr(+1, +-inf) and any NaN
+ * operand give NaN (pow() gives 1 / a signed value there).  ROCm's device returns exactly these NaNs (profiles/r02_ocl_builtin_gap.json).
+ * Dead code in the reference: only schlickDielectric (src/fresnel.cl:33) calls it and nothing calls that. */
+float b_native_powr(float x, float y) __asm__("_Z11native_powrff");
+float b_native_powr(float x, float y)
+{
+    if (x != x || y != y || x < 0.0f) return NAN;
+    if ((x == 0.0f || isinf(x)) && y == 0.0f) return NAN;
+    if (x == 1.0f && isinf(y)) return NAN;
+    return powf(x, y);
+}
 float3 b_native_recip3(float3 v) __asm__("_Z12native_recipDv3_f");
 float3 b_native_recip3(float3 v) { float3 r; r.x = 1.0f / v.x; r.y = 1.0f / v.y; r.z = 1.0f / v.z; return r; }
 float3 b_sqrt3(float3 v) __asm__("_Z4sqrtDv3_f");
@@ -81,7 +91,11 @@ float3 b_fmax3(float3 a, float3 b) __asm__("_Z4fmaxDv3_fS_");
 float3 b_fmax3(float3 a, float3 b) { float3 r; r.x = fmaxf(a.x, b.x); r.y = fmaxf(a.y, b.y); r.z = fmaxf(a.z, b.z); return r; }
 
 /* ---- integer / common (s6.12.3, s6.12.4) */
-float b_maxf(float a, float b) __asm__("_Z3maxff"); float b_maxf(float a, float b) { return a < b ? b : a; }
+/* max(float, float): "y if x < y, otherwise x", results undefined for NaN operands (s6.12.4).  ROCm's OpenCL compiles it to
+ * v_max_f32 = fmax (a NaN operand yields the other one; measured on the MI355X, profiles/r02_ocl_builtin_gap.json), and that is
+ * what the call sites with a possibly-NaN FIRST operand -- max(dot(areaLight.N, -L), 0.0f), src/wf_logic.cl:275 -- get on a real
+ * device; the literal "x < y ? y : x" would pass that NaN through. */
+float b_maxf(float a, float b) __asm__("_Z3maxff"); float b_maxf(float a, float b) { return fmaxf(a, b); }
 unsigned b_maxu(unsigned a, unsigned b) __asm__("_Z3maxjj"); unsigned b_maxu(unsigned a, unsigned b) { return a < b ? b : a; }
 unsigned b_minu(unsigned a, unsigned b) __asm__("_Z3minjj"); unsigned b_minu(unsigned a, unsigned b) { return b < a ? b : a; }
 int b_mini(int a, int b) __asm__("_Z3minii"); int b_mini(int a, int b) { return b < a ? b : a; }
@@ -109,7 +123,19 @@ float3 b_cross(float3 a, float3 b)
 float b_length3(float3 a) __asm__("_Z6lengthDv3_f");
 float b_length3(float3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
 float3 b_normalize3(float3 a) __asm__("_Z9normalizeDv3_f");
-float3 b_normalize3(float3 a) { float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); float3 r; r.x = a.x / l; r.y = a.y / l; r.z = a.z / l; return r; }
+/* OpenCL 1.2 s7.5.1 edge cases: normalize(v) returns v if all elements are zero; an infinite element is replaced by copysign(1, .) and
+ * every finite one by 0 * itself before proceeding; a NaN element makes the result NaN.  (Measured on the MI355X: exactly that.  The
+ * device additionally rescales so that |v| < 1e-19 or > 1e19 neither underflows nor overflows; such lengths do not occur on the path.) */
+float3 b_normalize3(float3 a)
+{
+    if (a.x == 0.0f && a.y == 0.0f && a.z == 0.0f) return a;
+    if (isinf(a.x) || isinf(a.y) || isinf(a.z)) {
+        a.x = isinf(a.x) ? copysignf(1.0f, a.x) : 0.0f * a.x;
+        a.y = isinf(a.y) ? copysignf(1.0f, a.y) : 0.0f * a.y;
+        a.z = isinf(a.z) ? copysignf(1.0f, a.z) : 0.0f * a.z;
+    }
+    float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); float3 r; r.x = a.x / l; r.y = a.y / l; r.z = a.z / l; return r;
+}
 
 /* ---- vload / vstore (s6.12.7) */
 float4 b_vload4(size_t off, const float *p) __asm__("_Z6vload4mPU8CLglobalKf");
