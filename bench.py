@@ -156,16 +156,13 @@ def main():
     ap.add_argument("--workload", default="kitchen", choices=sorted(WORKLOADS))
     ap.add_argument("--num-tasks", type=int, default=NUM_TASKS)
     ap.add_argument("--xcd-remap", type=int, default=0)
-    ap.add_argument("--trace-mode", type=int, default=0)
+    ap.add_argument("--extend-tree", type=int, default=4, choices=(2, 4), help="tree flx_wf_extend walks: 4-wide quantised (default) or the reference's binary tree (bit-exact)")
+    ap.add_argument("--shadow-tree", type=int, default=4, choices=(2, 4))
     ap.add_argument("--overlap", type=int, default=2)
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
     ap.add_argument("--kernel-timing", type=int, default=3, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel (roofline) only")
-    ap.add_argument("--stream-refill", type=int, default=24)
-    ap.add_argument("--stream-inner-min", type=int, default=24)
-    ap.add_argument("--stream-waves-ext", type=int, default=28)
-    ap.add_argument("--stream-waves-shadow", type=int, default=28)
     args = ap.parse_args()
 
     import torch
@@ -198,14 +195,11 @@ def main():
     for i in range(C):
         c_ = device.HipContext(args.num_tasks // C, device_index=local_rank)
         c_.set_option("xcd_remap", args.xcd_remap)
-        c_.set_option("trace_mode", args.trace_mode)
+        c_.set_option("extend_tree", args.extend_tree)
+        c_.set_option("shadow_tree", args.shadow_tree)
         c_.set_option("overlap", args.overlap)
         c_.set_option("node_layout", args.node_layout)
         c_.set_option("eager_bump", args.eager_bump)
-        c_.set_option("stream_refill", args.stream_refill)
-        c_.set_option("stream_inner_min", args.stream_inner_min)
-        c_.set_option("stream_waves_ext", args.stream_waves_ext)
-        c_.set_option("stream_waves_shadow", args.stream_waves_shadow)
         c_.upload_scene(d)
         c_.upload_envmap(env)
         c_.set_partition(rank * C + i, world * C)

@@ -1,6 +1,9 @@
 // api.hip -- the C ABI of libfluctus_hip.so (include/fluctus_hip.h): context, uploads with the
 // CDNA4 re-layout of the BVH, asynchronous kernel sequencing on one HIP stream, measurement hooks.
 #include "flx_device.h"
+#include "flx_wide.h"
+#include "flx_trace.h"
+#include "flx_trace4.h"
 #include "../../include/fluctus_hip.h"
 #include <string>
 #include <vector>
@@ -12,8 +15,8 @@
 namespace flxd {
 void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
-void launch_extend_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, float4 *, int, int, uint32_t, bool);
-void launch_shadow_stream(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int, int, uint32_t, bool);
+void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
+void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
@@ -65,18 +68,20 @@ struct flx_ctx {
     uint32_t *pinnedMk = nullptr; std::vector<std::pair<void *, int>> pendingMk; int nextMkSlot = 0;
     bool statsOn = false;
     int xcdRemap = 0;           // 1: each XCD gets a contiguous eighth of the queue (measured slower: round-robin keeps all XCDs on the same part of the tree)
-    int traceMode = 0;          // 0 = one thread per queue entry | 2, 3 = static-chunk refill variants (trace_stream.hip)
+    // which tree each traversal kernel walks: 2 = the reference's binary tree in the reference's visit order (bit-exact closest hit),
+    // 4 = the 4-wide quantised tree over the same leaves (flx_wide.h): any-hit bit-exact by construction, closest hit exact up to
+    // visit-order ties
+    int shadowTree = 4, extendTree = 4;
+    uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
+    bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
+    uint32_t spillLevels = 0;   // levels per lane in each spill buffer (sized at upload from the tree's depth)
     int eagerBump = 0;          // A/B: bump the extension counter right after raygen / materials (option eager_bump)
     int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
     std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
-    int streamInnerMin = 24;    // trace_mode 2: leave the descent loop when fewer lanes than this descend and leaves are pending
-    int streamRefill = 24;      // trace_mode 2: refill when at least this many lanes are idle
-    int streamWavesExt = 28, streamWavesShadow = 28;   // trace_mode 2: grid = CUs x this many waves
-    float4 *hitraw = nullptr;   // trace_mode 2: {t,u,v,tri} per extension-queue slot
     int numCUs = 256;
     // owned device allocations
-    std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs;
+    std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs, spillAllocs;
     // async counter read-back
     flx_queue_counters *pinned = nullptr; int pinnedSlots = 64, nextSlot = 0;
     uint32_t *pinnedIdx = nullptr; int nextIdxSlot = 0;
@@ -217,12 +222,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     const uint32_t blocks = (num_tasks + 255) / 256;
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * blocks) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * blocks))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->spill2, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->spill, (size_t)64 * (blocks * 256 + 1024))) return fail("hipMalloc(stack spill)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->hitraw, (size_t)num_tasks)) return fail("hipMalloc(hitraw)", hipErrorOutOfMemory);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
-    if (dalloc(c, c->fixedAllocs, &c->stats, 16)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
-    (void)hipMemsetAsync(c->stats, 0, 128, c->stream);
+    if (dalloc(c, c->fixedAllocs, &c->stats, FLX_NUM_TRACE_STATS)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
@@ -251,7 +253,7 @@ int flx_destroy(flx_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    freeAll(c->sceneAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->aovAllocs); freeAll(c->fixedAllocs);
+    freeAll(c->sceneAllocs); freeAll(c->spillAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->aovAllocs); freeAll(c->fixedAllocs);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
     if (c->pinnedMk) (void)hipHostFree(c->pinnedMk);
@@ -314,6 +316,8 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
             const uint32_t l = i + 1, r = nodes[i].iStartOrRight;
             NEED(c, l < nnodes && r < nnodes, "flx_upload_scene: child index out of range");
             const bool li = nodes[l].nPrims == 0, ri = nodes[r].nPrims == 0;
+            // an inner child that already has a record is reachable twice: cyclic or shared node array (e.g. a corrupt cache file)
+            NEED(c, !(li && innerId[l] >= 0) && !(ri && innerId[r] >= 0) && r > i, "flx_upload_scene: malformed node array (node reachable twice)");
             if (li && ri) { innerId[l] = (int32_t)nrecords; innerId[r] = (int32_t)nrecords + 1; nrecords += 2; }
             else if (li || ri) {
                 const uint32_t ch = li ? l : r;
@@ -369,21 +373,64 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         shade[i].c = make_float4(t.v2.n.x, t.v2.n.y, t.v2.n.z, t.v1.t.x);
         shade[i].d = make_float4(t.v1.t.y, t.v2.t.x, t.v2.t.y, fm);
     }
+    // 4. the 4-wide quantised tree over the same leaves (flx_wide.h) + the depth of the binary tree (stack-spill sizing)
+    flxw::WideTree wide;
+    { const char *werr = nullptr; if (!flxw::build_wide(nodes, nnodes, tris, ntris, indices, nidx, wide, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; } }
+    uint32_t binDepth = 1;
+    {   // nodes are in DFS order with parent < child (checked above for the right child; the left child is i + 1)
+        std::vector<uint16_t> depth(nnodes, 0);
+        for (size_t i = 0; i < nnodes; i++) {
+            if (nodes[i].nPrims != 0) continue;
+            const uint32_t l = (uint32_t)i + 1, r = nodes[i].iStartOrRight;
+            NEED(c, r > i && r < nnodes && l < nnodes, "flx_upload_scene: malformed node array");
+            const uint16_t dd = (uint16_t)(depth[i] + 1);
+            NEED(c, dd < 4096, "flx_upload_scene: tree deeper than 4095 levels");
+            depth[l] = dd; depth[r] = dd;
+            if (dd > binDepth) binDepth = dd;
+        }
+    }
+    uint32_t spillLevels = 1;
+    if (binDepth + 1 > LDS_LEVELS) spillLevels = binDepth + 1 - LDS_LEVELS;
+    // the 4-wide kernels page whole groups of 8 levels between their LDS ring and level-indexed spill rows (flx_trace4.h)
+    if (wide.maxStack > WIDE_LDS_LEVELS - 4 && wide.maxStack + 8 > spillLevels) spillLevels = wide.maxStack + 8;
+
+    // Allocate and fill the new scene first; the previous one is released (and c->sc switched) only when everything succeeded,
+    // so a failed upload leaves the context on its old scene instead of on dangling pointers.
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    std::vector<void *> fresh, freshSpill;
+    auto bail = [&]() { freeAll(fresh); freeAll(freshSpill); return 1; };
+    BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX; flxw::WNode *dW; float4 *dL;
+    if (dalloc(c, fresh, &dB, bnodes.size()) || dalloc(c, fresh, &dT, trirecs.size() + 1) || dalloc(c, fresh, &dS, shade.size()) ||
+        dalloc(c, fresh, &dTri, ntris) || dalloc(c, fresh, &dM, nmat) || dalloc(c, fresh, &dD, ntex) || dalloc(c, fresh, &dX, texbytes + 4) ||
+        dalloc(c, fresh, &dW, wide.nodes.size()) || dalloc(c, fresh, &dL, wide.leafdata.size() + 4))
+        return bail();
+    uint32_t *sp1 = c->spill, *sp2 = c->spill2;
+    const size_t lanes = ((size_t)c->numTasks + 255) / 256 * 256 + 1024;
+    const bool newSpill = spillLevels > c->spillLevels || !c->spill;
+    if (newSpill && (dalloc(c, freshSpill, &sp1, lanes * spillLevels) || dalloc(c, freshSpill, &sp2, lanes * spillLevels))) return bail();
+#define UPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(); } } while (0)
+    UPCHK(hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dS, shade.data(), shade.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dTri, tris, ntris * sizeof(flx_triangle), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dM, materials, nmat * sizeof(flx_material), hipMemcpyHostToDevice));
+    if (ntex) UPCHK(hipMemcpy(dD, texdesc, ntex * sizeof(flx_texdesc), hipMemcpyHostToDevice));
+    if (texbytes) UPCHK(hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dW, wide.nodes.data(), wide.nodes.size() * sizeof(flxw::WNode), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dL, wide.leafdata.data(), wide.leafdata.size() * sizeof(float4), hipMemcpyHostToDevice));
+#undef UPCHK
     freeAll(c->sceneAllocs);
-    BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX;
-    if (dalloc(c, c->sceneAllocs, &dB, bnodes.size()) || dalloc(c, c->sceneAllocs, &dT, trirecs.size() + 1) || dalloc(c, c->sceneAllocs, &dS, shade.size()) ||
-        dalloc(c, c->sceneAllocs, &dTri, ntris) || dalloc(c, c->sceneAllocs, &dM, nmat) || dalloc(c, c->sceneAllocs, &dD, ntex) || dalloc(c, c->sceneAllocs, &dX, texbytes + 4))
-        return 1;
-    HIPCHK(c, hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dS, shade.data(), shade.size() * sizeof(ShadeRec), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dTri, tris, ntris * sizeof(flx_triangle), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dM, materials, nmat * sizeof(flx_material), hipMemcpyHostToDevice));
-    if (ntex) HIPCHK(c, hipMemcpy(dD, texdesc, ntex * sizeof(flx_texdesc), hipMemcpyHostToDevice));
-    if (texbytes) HIPCHK(c, hipMemcpy(dX, texdata, texbytes, hipMemcpyHostToDevice));
+    c->sceneAllocs.swap(fresh);
+    if (newSpill) { freeAll(c->spillAllocs); c->spillAllocs.swap(freshSpill); c->spill = sp1; c->spill2 = sp2; c->spillLevels = spillLevels; }
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
+    c->sc.wnodes = dW; c->sc.wleaf = dL; c->sc.wrootRef = wide.rootRef;
+    // the exactness argument of the wide any-hit traversal needs nested boxes (flx_wide.h); a tree without them (no builder of
+    // ours or of the reference produces one) is traversed with the binary kernels
+    c->wideOK = wide.nested;
+    c->wideInfo[0] = (uint32_t)wide.nodes.size(); c->wideInfo[1] = (uint32_t)(wide.leafdata.size()); c->wideInfo[2] = wide.maxStack; c->wideInfo[3] = wide.nested ? 1u : 0u;
+    c->wideInfo[4] = binDepth; c->wideInfo[5] = spillLevels; c->wideInfo[6] = (uint32_t)bnodes.size(); c->wideInfo[7] = wide.maxLeafCount;
     return 0;
 }
 
@@ -444,7 +491,7 @@ int flx_wf_extend(flx_ctx *c)
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
-        if (c->traceMode >= 2) launch_extend_stream(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->hitraw, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesExt), c->traceMode == 3);
+        if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -475,7 +522,7 @@ int flx_wf_shadow(flx_ctx *c)
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
-        if (c->traceMode >= 2) launch_shadow_stream(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->streamRefill, c->streamInnerMin, (uint32_t)(c->numCUs * c->streamWavesShadow), c->traceMode == 3);
+        if (c->shadowTree == 4 && c->wideOK) launch_shadow4(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -637,7 +684,15 @@ int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int flx_trace_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, 128, c->stream)); return 0; }
+int flx_trace_stats_get_all(flx_ctx *c, uint64_t *out24)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out24, c->stats, FLX_NUM_TRACE_STATS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int flx_trace_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream)); return 0; }
+int flx_scene_info(flx_ctx *c, uint32_t *out8) { NEED(c, out8, "flx_scene_info: null"); memcpy(out8, c->wideInfo, 32); return 0; }
 
 // ---- test hooks
 int flx_state_export(flx_ctx *c, float *out)
@@ -695,7 +750,8 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
 {
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
-    if (name && strcmp(name, "trace_mode") == 0 && (value == 0 || value == 2 || value == 3)) { c->traceMode = value; return 0; }
+    if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->shadowTree = value; return 0; }
+    if (name && strcmp(name, "extend_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->extendTree = value; return 0; }
     if (name && strcmp(name, "denoiser") == 0 && (value == 0 || value == 1)) {
         MUTATES(c);
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
@@ -703,10 +759,6 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
-    if (name && strcmp(name, "stream_inner_min") == 0 && value >= 1 && value <= 64) { c->streamInnerMin = value; return 0; }
-    if (name && strcmp(name, "stream_refill") == 0 && value >= 1 && value <= 64) { c->streamRefill = value; return 0; }
-    if (name && strcmp(name, "stream_waves_ext") == 0 && value >= 1 && value <= 64) { c->streamWavesExt = value; return 0; }
-    if (name && strcmp(name, "stream_waves_shadow") == 0 && value >= 1 && value <= 64) { c->streamWavesShadow = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;
 }

@@ -89,6 +89,10 @@ struct Scene {
     const flx_texdesc *texdesc;
     const uint8_t *texdata;
     uint32_t rootRef;             // BNode 0 (inner) -- tiny scenes get a synthetic root
+    // 4-wide quantised tree over the same leaves (flx_wide.h): 64-B nodes, leaf blocks {exact box, count, triangles}
+    const void *wnodes;
+    const float4 *wleaf;
+    uint32_t wrootRef;
     // environment map
     const float4 *envRGBA;
     const float *probTable, *pdfTable;

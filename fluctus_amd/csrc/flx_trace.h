@@ -76,6 +76,42 @@ __device__ __forceinline__ bool light_quad(const flx_arealight &L, f3 orig, f3 d
     return hit;
 }
 
+// What traceExtension writes for one ray once the closest triangle is known (reference: src/wf_extrays.cl:22-35): the
+// shading attributes of the winning triangle interpolated at (u, v) (src/bvh.cl:271-279; the reference re-interpolates at
+// every commit, only the last one is observable), then the implicit area-light hit (src/wf_extrays.cl:28-29,
+// src/intersect.cl:124-155), pathLen += 1 and the 12 hit columns.  Shared by the binary and the 4-wide kernels.
+__device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, const flx_render_params &p, uint32_t gid, f3 orig, f3 dir, float pathLenBits,
+                                           float t, float u, float v, int tri, uint32_t &flags, int &matId)
+{
+    f3 P = mk3(0.0f), N = mk3(0.0f);
+    float tu = 0.0f, tv = 0.0f;
+    matId = -1;
+    flags = 0;
+    if (tri >= 0) {
+        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+        float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+        P = orig + t * dir;
+        N = normalize(bary(u, v, ld3(a), ld3(b), ld3(c)));
+        f3 uv = bary(u, v, mk3(a.w, b.w, 0.0f), mk3(c.w, d.x, 0.0f), mk3(d.y, d.z, 0.0f));
+        tu = uv.x; tv = uv.y;
+        matId = __float_as_int(d.w);
+    }
+    if (p.sampleImpl && p.useAreaLight) {
+        if (light_quad(p.areaLight, orig, dir, &t)) {
+            flags = 1u;
+            P = orig + t * dir;
+            N = V(p.areaLight.N);
+            tri = 0; matId = 0;
+        }
+    }
+    wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(pathLenBits) + 1u));          // pathLen += 1
+    wr4(st.at(S_HITP, gid), mk4(P, t));
+    // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
+    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;
+    wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
+    wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+}
+
 struct Stack {
     uint32_t *lds;          // this thread's column: lds[level * TRACE_BLOCK]
     uint32_t *spill;        // this thread's column: spill[(level - LDS_LEVELS) * totalThreads]

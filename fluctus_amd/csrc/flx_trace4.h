@@ -1,0 +1,168 @@
+// flx_trace4.h -- traversal of the 4-wide quantised tree (flx_wide.h) for gfx950.
+//
+// Node test.  With sd = s * dinv and od = (o - orig) * dinv per axis, plane q of a child has
+//     t(q) = fma(q, sd, od)                                   -- one v_cvt_f32_ubyteN + one v_fma_f32 per plane.
+// The reference's test of the child's EXACT box is T(b) = fl(fl(b - orig) * dinv) (src/intersect.cl:41-60).  The builder
+// guarantees (in real arithmetic) o + qlo s <= bmin and o + qhi s >= bmax, and with u = 2^-24, M = max |t| over the node's
+// grid on that axis, |t(q) - real| <= 3uM and |T(b) - real| <= 2uM, so shifting the near planes by -e and the far planes by
+// +e with e = 2^-21 (|od| + 256 |sd|) >= 8uM makes [tnear, tfar] a superset of the reference's interval on every axis: the
+// wide test passes whenever the reference's passes (same three conditions: tfar >= 0, tnear <= tfar, tnear < tMax).
+// dinv is clamped to +-2^100 for this test only (a zero direction component gives +-inf and 0 * inf = NaN planes that would
+// switch the axis off and let an axis-parallel ray wander through the whole slab of the scene); e, which grows with |sd|,
+// covers the boundary cases of that substitution.  Near / far planes are picked per axis by the sign of the direction with
+// one v_cndmask on the packed bytes of all four children.
+//
+// Leaf test: the leaf's exact fp32 box with the reference's arithmetic (slab(), the UNclamped 1/dir), then its triangles in
+// index-list order with the same Moller-Trumbore as the binary path.
+#pragma once
+#include "flx_trace.h"
+#include "flx_wide.h"
+
+namespace flxd {
+
+#ifndef WIDE_BLOCK
+#define WIDE_BLOCK 64
+#endif
+#ifndef WIDE_LDS_LEVELS
+#define WIDE_LDS_LEVELS 16          // stack entries kept in LDS per lane (4 KiB per wave); deeper entries spill to global memory
+#endif
+
+// Traversal stack: a RING of WIDE_LDS_LEVELS entries per lane in LDS ([slot][lane], conflict-free), holding stack levels
+// [base, base + WIDE_LDS_LEVELS); level L lives in slot L & (WIDE_LDS_LEVELS - 1).  Pushes are UNCONDITIONAL ds_writes followed by
+// sp += valid (no exec-mask branch per child); when a visit could overflow the window, the oldest 8 levels are paged out to the
+// global spill area, and paged back in when the window runs empty -- both rare, out of the hot path.
+// (the two paging routines are free functions with by-value arguments so that the stack descriptor stays in registers)
+__device__ __noinline__ void wstack_page_out(uint32_t *lds, uint32_t *spill, uint32_t stride, int base)
+{
+    for (int k = 0; k < 8; k++) spill[(size_t)(base + k) * stride] = lds[((base + k) & (WIDE_LDS_LEVELS - 1)) * WIDE_BLOCK];
+}
+__device__ __noinline__ void wstack_page_in(uint32_t *lds, const uint32_t *spill, uint32_t stride, int base)
+{
+    for (int k = 0; k < 8; k++) lds[((base + k) & (WIDE_LDS_LEVELS - 1)) * WIDE_BLOCK] = spill[(size_t)(base + k) * stride];
+}
+struct WStack {
+    uint32_t *lds;          // this lane's column: lds[slot * WIDE_BLOCK]
+    uint32_t *spill;        // this lane's column: spill[level * stride]
+    uint32_t stride;
+    int base;               // levels [0, base) live in the spill area; multiple of 8
+    __device__ __forceinline__ uint32_t &slot(int level) { return lds[(level & (WIDE_LDS_LEVELS - 1)) * WIDE_BLOCK]; }
+    __device__ __forceinline__ void put(int &sp, uint32_t v, bool valid) { slot(sp) = v; sp += valid ? 1 : 0; }
+    // room for 4 more entries
+    __device__ __forceinline__ void reserve(int sp) { if (sp - base > WIDE_LDS_LEVELS - 4) { wstack_page_out(lds, spill, stride, base); base += 8; } }
+    // pop; FLX_RAY_DONE when the stack is empty
+    __device__ __forceinline__ uint32_t pop(int &sp)
+    {
+        if (sp == base) { if (base == 0) return FLX_RAY_DONE; base -= 8; wstack_page_in(lds, spill, stride, base); }
+        return slot(--sp);
+    }
+};
+
+__device__ __forceinline__ float ub0(uint32_t v) { return (float)(v & 0xFFu); }
+__device__ __forceinline__ float ub1(uint32_t v) { return (float)((v >> 8) & 0xFFu); }
+__device__ __forceinline__ float ub2(uint32_t v) { return (float)((v >> 16) & 0xFFu); }
+__device__ __forceinline__ float ub3(uint32_t v) { return (float)(v >> 24); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float max3_(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+__device__ __forceinline__ float min3_(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+
+#define FLX_WIDE_DINV_MAX 1.2676506e30f          // 2^100
+
+// compare-exchange of (key, ref) pairs, ascending key
+#define FLX_CE(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; const uint32_t tr_ = sw_ ? rb : ra; \
+        kb = sw_ ? ka : kb; rb = sw_ ? ra : rb; ka = tk_; ra = tr_; } while (0)
+
+template <bool ANY_HIT, bool STATS>
+__device__ __forceinline__ bool traverse4(const Scene &sc, WStack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
+                                          int &tribest, uint32_t &nInner, uint32_t &nTri, uint32_t &nLeaf, unsigned long long *wstats = nullptr)
+{
+#define FLX_WAVE_TICK(k) do { if (STATS && wstats) { const uint64_t m_ = __ballot(true); \
+        if (lane_id() == (uint32_t)__ffsll((long long)m_) - 1u) atomicAdd(&wstats[k], 1ull); } } while (0)
+    const f3 dinv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);                 // the reference's native_recip(dir): leaf boxes
+    const float dwx = fminf_(fmaxf_(dinv.x, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
+    const float dwy = fminf_(fmaxf_(dinv.y, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
+    const float dwz = fminf_(fmaxf_(dinv.z, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
+    const bool negx = (__float_as_uint(dwx) >> 31) != 0u, negy = (__float_as_uint(dwy) >> 31) != 0u, negz = (__float_as_uint(dwz) >> 31) != 0u;
+    const float4 *wn = reinterpret_cast<const float4 *>(sc.wnodes);
+    int sp = 0;
+    uint32_t cur = sc.wrootRef;
+    for (;;) {
+        FLX_WAVE_TICK(0);
+        while (!(cur & FLX_WIDE_LEAF_BIT)) {
+            FLX_WAVE_TICK(1);
+            const float4 *np = wn + (size_t)cur * 4;
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (STATS) nInner++;
+            const float sdx = n0.w * dwx, sdy = n1.x * dwy, sdz = n1.y * dwz;
+            const float odx = (n0.x - orig.x) * dwx, ody = (n0.y - orig.y) * dwy, odz = (n0.z - orig.z) * dwz;
+            const float ex = 4.76837158e-7f * fma_(absf(sdx), 256.0f, absf(odx));      // 2^-21 (|od| + 256 |sd|)
+            const float ey = 4.76837158e-7f * fma_(absf(sdy), 256.0f, absf(ody));
+            const float ez = 4.76837158e-7f * fma_(absf(sdz), 256.0f, absf(odz));
+            const float onx = odx - ex, ofx = odx + ex, ony = ody - ey, ofy = ody + ey, onz = odz - ez, ofz = odz + ez;
+            const uint32_t qlox = __float_as_uint(n2.z), qloy = __float_as_uint(n2.w), qloz = __float_as_uint(n3.x);
+            const uint32_t qhix = __float_as_uint(n3.y), qhiy = __float_as_uint(n3.z), qhiz = __float_as_uint(n3.w);
+            const uint32_t qnx = negx ? qhix : qlox, qfx = negx ? qlox : qhix;
+            const uint32_t qny = negy ? qhiy : qloy, qfy = negy ? qloy : qhiy;
+            const uint32_t qnz = negz ? qhiz : qloz, qfz = negz ? qloz : qhiz;
+            uint32_t r0 = __float_as_uint(n1.z), r1 = __float_as_uint(n1.w), r2 = __float_as_uint(n2.x), r3 = __float_as_uint(n2.y);
+#define FLX_CHILD(UB, REF, KEY, HIT) \
+            { const float tn = max3_(fma_(UB(qnx), sdx, onx), fma_(UB(qny), sdy, ony), fma_(UB(qnz), sdz, onz)); \
+              const float tf = min3_(fma_(UB(qfx), sdx, ofx), fma_(UB(qfy), sdy, ofy), fma_(UB(qfz), sdz, ofz)); \
+              const float tn0 = fmaxf_(tn, 0.0f); \
+              HIT = (tn0 <= tf) && (tn < tbest) && (REF != FLX_WIDE_EMPTY); KEY = tn0; }
+            float k0, k1, k2, k3; bool h0, h1, h2, h3;
+            FLX_CHILD(ub0, r0, k0, h0)
+            FLX_CHILD(ub1, r1, k1, h1)
+            FLX_CHILD(ub2, r2, k2, h2)
+            FLX_CHILD(ub3, r3, k3, h3)
+#undef FLX_CHILD
+            stk.reserve(sp);
+            if (ANY_HIT) {
+                // order-free: continue with the LAST hit child, push the earlier ones
+                const bool p0 = h0 && (h1 || h2 || h3), p1 = h1 && (h2 || h3), p2 = h2 && h3;
+                stk.put(sp, r0, p0); stk.put(sp, r1, p1); stk.put(sp, r2, p2);
+                if (h0 || h1 || h2 || h3) cur = h3 ? r3 : (h2 ? r2 : (h1 ? r1 : r0));
+                else cur = stk.pop(sp);
+            } else {
+                // nearest first: sort the four (entry distance, ref) pairs, misses at +inf
+                const float INF = __builtin_huge_valf();
+                k0 = h0 ? k0 : INF; k1 = h1 ? k1 : INF; k2 = h2 ? k2 : INF; k3 = h3 ? k3 : INF;
+                FLX_CE(k0, r0, k1, r1); FLX_CE(k2, r2, k3, r3); FLX_CE(k0, r0, k2, r2); FLX_CE(k1, r1, k3, r3); FLX_CE(k1, r1, k2, r2);
+                stk.put(sp, r3, k3 < INF); stk.put(sp, r2, k2 < INF); stk.put(sp, r1, k1 < INF);
+                if (k0 < INF) cur = r0;
+                else cur = stk.pop(sp);
+            }
+        }
+        if (cur == FLX_RAY_DONE) break;
+        {
+            const float4 *lp = sc.wleaf + (cur & FLX_WIDE_OFF_MASK);
+            const float4 b0 = lp[0], b1 = lp[1];
+            FLX_WAVE_TICK(2);
+            if (STATS) nLeaf++;
+            const float bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b1.x, b1.y, b1.z};
+            float tnear;
+            if (slab(bmin, bmax, orig, dinv, tbest, &tnear)) {         // the reference's own test of the leaf node's box
+                const int count = __float_as_int(b0.w);
+                const float4 *tp = lp + 2;
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                for (int k = 0;;) {
+                    FLX_WAVE_TICK(3);
+                    if (STATS) nTri++;
+                    float t, u, v;
+                    if (moller_trumbore(orig, dir, ld3(a), ld3(b), ld3(c), &t, &u, &v) && t > 0.0f && t < tbest) {
+                        if (ANY_HIT) return true;
+                        tbest = t; ubest = u; vbest = v; tribest = __float_as_int(a.w);
+                    }
+                    if (++k >= count) break;
+                    tp += 3;
+                    a = tp[0]; b = tp[1]; c = tp[2];
+                }
+            }
+        }
+        cur = stk.pop(sp);
+        if (cur == FLX_RAY_DONE) break;
+    }
+    return false;
+#undef FLX_WAVE_TICK
+}
+
+} // namespace flxd

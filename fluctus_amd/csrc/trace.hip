@@ -45,35 +45,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES) void k_extend(State s
     uint32_t nInner = 0, nTri = 0;
     traverse<false, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri, STATS ? aux.stats + 8 : nullptr);
 
-    // commit: shading attributes of the winning triangle (reference: src/bvh.cl:271-279)
-    f3 P = mk3(0.0f), N = mk3(0.0f);
-    float tu = 0.0f, tv = 0.0f;
-    int matId = -1;
-    uint32_t flags = 0;
-    if (tri >= 0) {
-        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
-        float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
-        P = orig + t * dir;
-        N = normalize(bary(u, v, ld3(a), ld3(b), ld3(c)));
-        f3 uv = bary(u, v, mk3(a.w, b.w, 0.0f), mk3(c.w, d.x, 0.0f), mk3(d.y, d.z, 0.0f));
-        tu = uv.x; tv = uv.y;
-        matId = __float_as_int(d.w);
-    }
-    // implicit area-light hit (reference: src/wf_extrays.cl:28-29, src/intersect.cl:124-155)
-    if (p.sampleImpl && p.useAreaLight) {
-        if (light_quad(p.areaLight, orig, dir, &t)) {
-            flags = 1u;
-            P = orig + t * dir;
-            N = V(p.areaLight.N);
-            tri = 0; matId = 0;
-        }
-    }
-    wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(d4.w) + 1u));          // pathLen += 1
-    wr4(st.at(S_HITP, gid), mk4(P, t));
-    // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
-    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;
-    wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
-    wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+    uint32_t flags; int matId;
+    commit_hit(st, sc, p, gid, orig, dir, d4.w, t, u, v, tri, flags, matId);
 
     if (STATS) {
         bool hitGeom = matId >= 0 && !(flags & 1u);

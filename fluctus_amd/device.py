@@ -19,7 +19,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
-           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
+           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
@@ -206,6 +206,18 @@ class HipContext:
         self._chk(self.L.flx_trace_stats_get(self.h, _p(out)))
         return dict(ext_rays=int(out[0]), ext_inner=int(out[1]), ext_tri=int(out[2]), ext_hits=int(out[3]),
                     shadow_inner=int(out[4]), shadow_tri=int(out[5]), shadow_rays=int(out[6]))
+
+    def leaf_stats(self):
+        """Leaf visits of the extension / shadow traversal (wide kernels only)."""
+        out = np.zeros(24, np.uint64)
+        self._chk(self.L.flx_trace_stats_get_all(self.h, _p(out)))
+        return dict(ext_leaf=int(out[16]), shadow_leaf=int(out[17]))
+
+    def scene_info(self):
+        out = np.zeros(8, np.uint32)
+        self._chk(self.L.flx_scene_info(self.h, _p(out)))
+        k = ("wide_nodes", "wide_leaf_f4", "wide_stack_bound", "nested", "binary_depth", "spill_levels", "binary_records", "max_leaf")
+        return {n: int(v) for n, v in zip(k, out)}
 
     def wave_stats(self):
         """Wave-level trip counts of the traversal loops (see flx_trace_stats_get_ex)."""

@@ -99,6 +99,7 @@ void HipContext::foldMkStats()
 }
 // The reference rebuilds every kernel with / without -DUSE_OPTIX_DENOISER; here the kernels branch on the presence of
 // the feature buffers, so "recompiling" is allocating or freeing them.
+void HipContext::setOption(const std::string &name, int value) { check(api->flx_set_option(ctx, name.c_str(), value), "setOption"); }
 void HipContext::recompileKernels(bool useDenoiser) { check(api->flx_set_option(ctx, "denoiser", useDenoiser ? 1 : 0), "recompileKernels"); }
 void HipContext::enqueueClearWfQueues() { check(api->flx_clear_queues(ctx), "clear queues"); }
 void HipContext::enqueueGetCounters(QueueCounters *cnt) { check(api->flx_get_counters_async(ctx, cnt), "get counters"); }

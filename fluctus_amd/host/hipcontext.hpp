@@ -44,6 +44,9 @@ public:
     void enqueueSplatPreviewKernel(const RenderParams &params);
     void fetchStatsAsync();                                       // src/clcontext.cpp:642-646; folded into statsAsync by finishQueue()
     void recompileKernels(bool useDenoiser);                      // src/clcontext.cpp:852-874: here only the denoiser-feature switch
+    // kernel selection the reference makes through Settings + recompile (src/settings.cpp): "extend_tree" / "shadow_tree" 2 | 4, ...
+    // (include/fluctus_hip.h, flx_set_option)
+    void setOption(const std::string &name, int value);
     void enqueueClearWfQueues();                                  // src/clcontext.cpp:877-883
     void enqueueGetCounters(QueueCounters *cnt);                  // async; valid after finishQueue()
     void enqueuePostprocessKernel(const RenderParams &params);

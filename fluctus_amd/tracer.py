@@ -52,6 +52,10 @@ class Tracer:
     def set_denoiser(self, on):
         host._chk(self.L.fh_tracer_set_denoiser(self.h, int(bool(on))))
 
+    def set_option(self, name, value):
+        """HipContext::setOption -> flx_set_option (e.g. "extend_tree", 2 for the reference's bit-exact visit order)."""
+        host._chk(self.L.fh_tracer_set_option(self.h, name.encode(), int(value)))
+
     def toggle_renderer(self):
         host._chk(self.L.fh_tracer_toggle_renderer(self.h))
 

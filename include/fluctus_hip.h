@@ -143,7 +143,13 @@ int flx_trace_stats_get(flx_ctx *ctx, uint64_t *out7);
  * {outer iterations, inner-node branch executions, leaf branch executions, triangle-loop trips}; SIMD efficiency of
  * the traversal = lane-level visits / (64 x wave-level trips) */
 int flx_trace_stats_get_ex(flx_ctx *ctx, uint64_t *out16);
+/* the 16 above + out24[16] / [17]: leaf visits of the extension / shadow traversal ([18..23] reserved) */
+#define FLX_NUM_TRACE_STATS 24
+int flx_trace_stats_get_all(flx_ctx *ctx, uint64_t *out24);
 int flx_trace_stats_reset(flx_ctx *ctx);
+/* what flx_upload_scene built: out8 = {wide nodes, wide leaf data (16-byte units), wide traversal-stack bound, boxes nested (1/0),
+ * binary tree depth, spill levels per lane, binary inner-node records, largest leaf} */
+int flx_scene_info(flx_ctx *ctx, uint32_t *out8);
 
 /* ---- test hooks: path state in the reference's GPUTaskState SoA layout (64 columns x num_tasks
  * words, src/geom.h:199-236), queues and counters.  Blocking. */
@@ -152,15 +158,19 @@ int flx_state_import(flx_ctx *ctx, const float *in_64xN);
 int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
 int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);
 int flx_set_counters(flx_ctx *ctx, const void *in32);
-/* tuning knobs (kernel variants, all bit-identical in their results); see DESIGN.md 4.1.  Unknown names fail.
- *   trace_mode        0 thread per ray (default) | 2 static-chunk refill, threshold descent | 3 static-chunk refill,
- *                     unified work items (both measured slower, kept for A/B: DESIGN.md 4.1)
+/* options.  Unknown names fail.
+ *   shadow_tree       4 (default): flx_wf_shadow walks the 4-wide quantised tree built at upload over the reference tree's leaves
+ *                     (csrc/flx_wide.h) -- bit-identical results to the binary tree (order-free query, conservative boxes, exact
+ *                     leaf test) | 2: the reference's binary tree
+ *   extend_tree       4 (default): flx_wf_extend on the 4-wide tree -- same closest hit except where the visit ORDER decides
+ *                     (exact ties in t, box-vs-triangle rounding near-ties; SURVEY 8(c) budgets <= 1e-5 of rays, measured in
+ *                     DESIGN.md 4.1) | 2: the reference's binary tree in the reference's visit order (bit-exact)
  *   overlap           0 serial | 1 flx_wf_shadow directly after flx_wf_extend runs concurrently with it on a second stream |
  *                     2 (default) as 1, and it starts as soon as `logic` is done when only raygen / materials / extend
  *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip)
- *   node_layout       1 (default) sibling-pair record numbering | 0 DFS numbering; takes effect at the next flx_upload_scene
+ *   node_layout       1 (default) sibling-pair record numbering of the binary tree | 0 DFS numbering; takes effect at the next flx_upload_scene
  *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
- *   xcd_remap, eager_bump, stream_refill, stream_inner_min, stream_waves_ext, stream_waves_shadow: A/B knobs */
+ *   xcd_remap, eager_bump: A/B knobs of the binary kernels */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
 
 #ifdef __cplusplus

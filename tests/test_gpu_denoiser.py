@@ -12,6 +12,7 @@ def _ctxs(d, p, n, env=None, overlap=2):
     from fluctus_amd.device import HipContext
     from oracle.binding import OracleContext
     g, o = HipContext(n), OracleContext(n, threads=8)
+    g.set_option("extend_tree", 2)          # bit-exact comparisons: the reference's visit order
     g.set_option("overlap", overlap)
     for c in (g, o):
         c.set_option("denoiser", 1)

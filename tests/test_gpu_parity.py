@@ -15,15 +15,16 @@ from fluctus_amd import host, wire, driver
 pytestmark = pytest.mark.gpu
 
 
-TRACE_MODE = {"mode": 0, "thresh": 24, "xcd": 0, "overlap": 2}
+TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2}
 
 
-# (trace_mode, refill threshold, xcd_remap, overlap): every kernel variant and stream schedule must give the same bits
-@pytest.fixture(params=[(0, 24, 0, 2), (0, 24, 1, 1), (0, 24, 0, 0), (2, 24, 0, 2), (2, 1, 0, 0), (2, 64, 0, 1), (3, 24, 0, 2), (3, 1, 0, 1), (3, 64, 0, 0)],
-                ids=["thread-per-ray", "thread-per-ray-xcdremap-overlap1", "thread-per-ray-serial", "stream-refill24", "stream-refill1-serial",
-                     "stream-refill64-overlap1", "flow-refill24", "flow-refill1-overlap1", "flow-refill64-serial"], autouse=True)
+# (extend_tree, shadow_tree, xcd_remap, overlap): every tree / stream schedule that claims bit-exactness must give the same bits.
+# extend_tree is 2 throughout (the reference's visit order); the 4-wide closest-hit kernel is order-dependent in exact ties and
+# has its own tests with a flip count (tests/test_gpu_wide.py).  shadow_tree 4 (the default) is exact by construction.
+@pytest.fixture(params=[(2, 4, 0, 2), (2, 2, 1, 1), (2, 2, 0, 0), (2, 4, 0, 0), (2, 4, 0, 1)],
+                ids=["wide-shadow", "binary-shadow-xcdremap-overlap1", "binary-shadow-serial", "wide-shadow-serial", "wide-shadow-overlap1"], autouse=True)
 def trace_mode(request):
-    TRACE_MODE["mode"], TRACE_MODE["thresh"], TRACE_MODE["xcd"], TRACE_MODE["overlap"] = request.param
+    TRACE_MODE["ext"], TRACE_MODE["shadow"], TRACE_MODE["xcd"], TRACE_MODE["overlap"] = request.param
     yield
 
 
@@ -31,8 +32,8 @@ def _ctxs(d, p, n, env=None):
     from fluctus_amd.device import HipContext
     from oracle.binding import OracleContext
     g, o = HipContext(n), OracleContext(n, threads=8)
-    g.set_option("trace_mode", TRACE_MODE["mode"])
-    g.set_option("stream_refill", TRACE_MODE["thresh"])
+    g.set_option("extend_tree", TRACE_MODE["ext"])
+    g.set_option("shadow_tree", TRACE_MODE["shadow"])
     g.set_option("overlap", TRACE_MODE["overlap"])
     g.set_option("xcd_remap", TRACE_MODE["xcd"])
     for c in (g, o):
@@ -148,6 +149,7 @@ def test_golden_fixture_teapot():
     p = z["params"].view(wire.RENDER_PARAMS).reshape(())
     w, h = int(p["width"]), int(p["height"])
     g = HipContext(int(z["num_tasks"]))
+    g.set_option("extend_tree", TRACE_MODE["ext"]); g.set_option("shadow_tree", TRACE_MODE["shadow"])
     g.upload_scene(d); g.set_params(p); driver.reset_renderer(g)
     cnts = z["counters"]
     for it in range(cnts.shape[0]):
@@ -197,18 +199,21 @@ def test_large_queue_properties():
 def test_full_size_properties_and_determinism(workload):
     """BASELINE.json configs[1..4] at full size (kitchen-proc ~0.5 M triangles 1920x1080 8 bounces env-map MIS; conference-proc
     GGX + area light; courtyard-proc 8.9 M triangles 2560x1440 12 bounces and 3840x2160 16 bounces, all BSDFs), 1 M paths: too big for the oracle, so
-    size-independent properties are checked, and two independent runs -- different stream schedules -- must agree bit for bit."""
+    size-independent properties are checked, and two independent runs -- different stream schedules AND different any-hit trees
+    (4-wide quantised vs the reference's binary tree) -- must agree bit for bit."""
     from fluctus_amd.device import HipContext
     import bench
-    if workload != "kitchen" and (TRACE_MODE["mode"] != 0 or TRACE_MODE["xcd"] or TRACE_MODE["overlap"] != 2):
-        pytest.skip("the A/B kernel variants are exercised at full size on the kitchen scene only")
+    if workload != "kitchen" and (TRACE_MODE["shadow"] != 4 or TRACE_MODE["xcd"] or TRACE_MODE["overlap"] != 2):
+        pytest.skip("the A/B variants are exercised at full size on the kitchen scene only")
     d, p, env = bench.build_workload(name=workload)
     n, npix = 1 << 20, int(p["width"]) * int(p["height"])
     outs = []
     for run in range(2):
         g = HipContext(n)
-        g.set_option("trace_mode", TRACE_MODE["mode"])
-        g.set_option("overlap", TRACE_MODE["overlap"] if run == 0 else 0)      # second run fully serial: same bits
+        g.set_option("extend_tree", TRACE_MODE["ext"])
+        # second run: the BINARY any-hit traversal and a fully serial schedule -- same bits as the 4-wide / overlapped first run
+        g.set_option("shadow_tree", TRACE_MODE["shadow"] if run == 0 else 2)
+        g.set_option("overlap", TRACE_MODE["overlap"] if run == 0 else 0)
         g.upload_scene(d); g.upload_envmap(env); g.set_params(p); driver.reset_renderer(g)
         cnts = []
         for it in range(12):
@@ -330,7 +335,7 @@ def test_device_vs_reference_kernel_outputs(tag):
     d.texdesc = z["texdesc"].view(wire.TEXDESC).reshape(-1); d.texdata = z["texdata"]
     e = host.EnvMap(int(z["env_wh"][0]), int(z["env_wh"][1]), z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])
     g = HipContext(n)
-    g.set_option("trace_mode", TRACE_MODE["mode"])
+    g.set_option("extend_tree", TRACE_MODE["ext"]); g.set_option("shadow_tree", TRACE_MODE["shadow"])
     den = "aov" in z.files                         # fixture made with the reference's USE_OPTIX_DENOISER kernel builds
     if den:
         g.set_option("denoiser", 1)

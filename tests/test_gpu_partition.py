@@ -21,6 +21,7 @@ def _ctxs(d, p, n, rank, world, env=None):
     from fluctus_amd.device import HipContext
     from oracle.binding import OracleContext
     g, o = HipContext(n), OracleContext(n, threads=8)
+    g.set_option("extend_tree", 2)          # bit-exact comparisons: the reference's visit order
     for c in (g, o):
         c.upload_scene(d)
         if env is not None:

@@ -21,6 +21,7 @@ def test_cpp_tracer_update_matches_oracle(tmp_path):
     w, h, n = 96, 64, 8192
     scene = "proc:conference:12000:43"
     t = Tracer(w, h, 0, n)
+    t.set_option("extend_tree", 2)          # the reference's visit order: counters and image compared exactly below
     t.init(w, h, scene)
     p = t.params
     wire.look_at(p, (0.0, 1.2, 2.6), (0.0, 0.2, 0.0))
