@@ -72,6 +72,7 @@ struct flx_ctx {
     // 4 = the 4-wide quantised tree over the same leaves (flx_wide.h): any-hit bit-exact by construction, closest hit exact up to
     // visit-order ties
     int shadowTree = 4, extendTree = 4;
+
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
     uint32_t spillLevels = 0;   // levels per lane in each spill buffer (sized at upload from the tree's depth)

@@ -24,7 +24,7 @@
 namespace flxw {
 
 #define FLX_WIDE_LEAF_BIT 0x80000000u
-#define FLX_WIDE_EMPTY    0xFFFFFFFEu          // unused child slot (leaf bit set: never descended into)
+#define FLX_WIDE_EMPTY    (FLX_WIDE_LEAF_BIT | 0u)   // unused child slot = the dummy leaf at offset 0 of the leaf data (cannot be hit)
 #define FLX_WIDE_OFF_MASK 0x7FFFFFFFu
 
 // 64 B, 64-B aligned.  Plane k of child c on axis a:  o[a] + q * s[a],  q = byte c of qlo[a] / qhi[a].
@@ -64,8 +64,19 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
     {
         size_t total = 0;
         for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims) total += 2 + 3 * (size_t)nodes[i].nPrims;
+        total += 5;
         if (total >= FLX_WIDE_OFF_MASK) return fail("wide tree: leaf data exceeds the 31-bit offset range");
-        out.leafdata.reserve(total);
+        out.leafdata.reserve(total + 5);
+        // dummy leaf for unused child slots: a point box far outside every scene and one degenerate triangle (det == 0: never hit).
+        // An unused slot's quantised box is inverted (lo plane 255, hi plane 0) and fails the node test except for rays more than
+        // ~2^28 grid cells away (the conservative shift e); those land here and find nothing.
+        {
+            int one = 1; float fc; memcpy(&fc, &one, 4);
+            int none = -1; float fn; memcpy(&fn, &none, 4);
+            const float F = 3.0e38f;
+            out.leafdata.push_back({F, F, F, fc}); out.leafdata.push_back({F, F, F, 0.0f});
+            out.leafdata.push_back({F, F, F, fn}); out.leafdata.push_back({F, F, F, 0.0f}); out.leafdata.push_back({F, F, F, 0.0f});
+        }
         for (size_t i = 0; i < nnodes; i++) {
             const flx_node &n = nodes[i];
             if (!n.nPrims) continue;
