@@ -338,6 +338,21 @@ def main():
         full = multi.gather_tiles(tile, args.width * args.height, rank, world)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        # the same gather through the library's own RCCL group (flx_group_init / flx_gather: what the C++ host uses), id shipped by torch
+        native_ms = native_ok = None
+        if C == 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(device.group_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            ctxs[0].group_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+            dist.barrier()
+            n0 = time.perf_counter()
+            full_native = ctxs[0].gather(0)
+            native_ms = (time.perf_counter() - n0) * 1e3
+            if rank == 0:
+                native_ok = bool(np.array_equal(full_native, full.cpu().numpy()))
+                assert native_ok, "flx_gather differs from torch.distributed.gather"
         gather_ok = None
         if rank == 0:
             assert torch.isfinite(full).all() and lp > 0
@@ -380,6 +395,8 @@ def main():
         if gather_ms is not None:
             line["gather_ms"] = gather_ms
             line["gather_matches_read_pixels"] = gather_ok
+            line["gather_ms_native_rccl"] = native_ms
+            line["gather_native_matches_torch"] = native_ok
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
             if line["cpu_baseline"]["kind"] == "reference":      # the oracle port beside it (order-preserving appends instead of per-path atomics)

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <utility>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 is bound with dlopen at the first group call
 
 namespace flxd {
 void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
@@ -31,6 +33,7 @@ void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const Fram
 void launch_mk_splat(hipStream_t, const State &, const Frame &, const flx_render_params &, uint32_t *, int);
 void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t, uint32_t);
 void launch_bump_extension(hipStream_t, uint32_t *, uint32_t);
+void launch_deinterleave(hipStream_t, const float *, float *, uint32_t, uint32_t, uint32_t);
 }
 
 using namespace flxd;
@@ -81,6 +84,11 @@ struct flx_ctx {
     std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
     int numCUs = 256;
+    // multi-GPU group (flx_group_*): RCCL communicator of this rank, root-side staging
+    ncclComm_t comm = nullptr;
+    bool commShared = false;                    // same-device local group: no communicator, device copies instead
+    float *gatherStage = nullptr, *gatherFull = nullptr; size_t gatherStageFloats = 0, gatherFullFloats = 0;
+    std::vector<void *> gatherAllocs;
     // owned device allocations
     std::vector<void *> sceneAllocs, envAllocs, frameAllocs, fixedAllocs, spillAllocs;
     // async counter read-back
@@ -254,6 +262,8 @@ int flx_destroy(flx_ctx *c)
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { flx_group_destroy(c); }
+    freeAll(c->gatherAllocs);
     freeAll(c->sceneAllocs); freeAll(c->spillAllocs); freeAll(c->envAllocs); freeAll(c->frameAllocs); freeAll(c->aovAllocs); freeAll(c->fixedAllocs);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinnedIdx) (void)hipHostFree(c->pinnedIdx);
@@ -664,6 +674,190 @@ int flx_copy_pixels_to_device(flx_ctx *c, void *dst)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
     return 0;
+}
+
+
+// ---- multi-GPU group: RCCL gather of the per-rank radiance tiles (SURVEY 8(b) flx_create_group / flx_gather, 8(e)).
+// The reference is single-device (one cl::CommandQueue, src/clcontext.cpp:25-29).  Rank r renders global pixels p * R + r
+// (flx_set_partition); at read-back every rank sends its compact float4[localPixels] accumulation tile to the root over
+// RCCL point-to-point (grouped ncclSend / ncclRecv = a gather; xGMI links into the root work in parallel), the root
+// de-interleaves into the full image.  Nothing is exchanged per iteration.
+namespace {
+struct Rccl {
+    void *dl = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+Rccl g_rccl;
+bool rccl_load()
+{
+    if (g_rccl.dl) return true;
+    void *dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!dl) { g_rccl.err = std::string("librccl.so.1 not loadable: ") + dlerror(); return false; }
+#define RSYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(dl, #name); if (!g_rccl.field) { g_rccl.err = "librccl: missing symbol " #name; dlclose(dl); return false; }
+    RSYM(GetUniqueId, ncclGetUniqueId) RSYM(CommInitRank, ncclCommInitRank) RSYM(CommInitAll, ncclCommInitAll) RSYM(CommDestroy, ncclCommDestroy)
+    RSYM(Send, ncclSend) RSYM(Recv, ncclRecv) RSYM(GroupStart, ncclGroupStart) RSYM(GroupEnd, ncclGroupEnd) RSYM(GetErrorString, ncclGetErrorString)
+#undef RSYM
+    g_rccl.dl = dl;
+    return true;
+}
+}
+#define NCCLCHK(c, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { (c)->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_); return 1; } } while (0)
+
+static uint32_t tilePixels(uint32_t npix, uint32_t rank, uint32_t nranks) { return npix <= rank ? 0u : (npix - rank + nranks - 1) / nranks; }
+
+int flx_group_unique_id(void *out128)
+{
+    if (!out128 || !rccl_load()) { g_create_error = out128 ? g_rccl.err : "flx_group_unique_id: null"; return 1; }
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return 1; }
+    static_assert(sizeof(ncclUniqueId) == FLX_GROUP_ID_BYTES, "ncclUniqueId size");
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int flx_group_destroy(flx_ctx *c)
+{
+    if (c->comm && g_rccl.dl) { (void)hipSetDevice(c->device); (void)g_rccl.CommDestroy(c->comm); }
+    c->comm = nullptr; c->commShared = false;
+    return 0;
+}
+
+int flx_group_init(flx_ctx *c, uint32_t rank, uint32_t nranks, const void *id128)
+{
+    MUTATES(c);
+    NEED(c, id128 && nranks >= 1 && rank < nranks, "flx_group_init: bad arguments");
+    NEED(c, rccl_load(), g_rccl.err);
+    HIPCHK(c, hipSetDevice(c->device));
+    flx_group_destroy(c);
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    NCCLCHK(c, g_rccl.CommInitRank(&c->comm, (int)nranks, id, (int)rank));
+    return flx_set_partition(c, rank, nranks);
+}
+
+int flx_group_init_local(flx_ctx **ctxs, uint32_t n)
+{
+    if (!ctxs || !n || !ctxs[0]) { g_create_error = "flx_group_init_local: bad arguments"; return 1; }
+    flx_ctx *c0 = ctxs[0];
+    bool distinct = true;
+    for (uint32_t i = 0; i < n; i++) { NEED(c0, ctxs[i], "flx_group_init_local: null context"); for (uint32_t j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false; }
+    for (uint32_t i = 0; i < n; i++) { MUTATES(ctxs[i]); flx_group_destroy(ctxs[i]); }
+    if (distinct) {
+        NEED(c0, rccl_load(), g_rccl.err);
+        std::vector<ncclComm_t> comms(n); std::vector<int> devs(n);
+        for (uint32_t i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+        NCCLCHK(c0, g_rccl.CommInitAll(comms.data(), (int)n, devs.data()));
+        for (uint32_t i = 0; i < n; i++) ctxs[i]->comm = comms[i];
+    } else {
+        // several contexts on one device (a 1-GPU box standing in for N ranks: tests): RCCL refuses duplicate devices, the tiles
+        // travel with device-to-device copies instead; partition, staging and de-interleave are the same code
+        for (uint32_t i = 0; i < n; i++) ctxs[i]->commShared = true;
+    }
+    for (uint32_t i = 0; i < n; i++) if (flx_set_partition(ctxs[i], i, n)) { if (ctxs[i] != c0) c0->err = ctxs[i]->err; return 1; }
+    return 0;
+}
+
+static int gatherBuffers(flx_ctx *root, uint32_t nranks)
+{
+    const uint32_t npix = root->params.width * root->params.height;
+    const size_t maxlp = tilePixels(npix, 0, nranks);
+    const size_t needStage = (size_t)nranks * maxlp * 4, needFull = (size_t)npix * 4;
+    if (needStage > root->gatherStageFloats || needFull > root->gatherFullFloats) {
+        HIPCHK(root, hipStreamSynchronize(root->stream));
+        freeAll(root->gatherAllocs);
+        root->gatherStageFloats = root->gatherFullFloats = 0;
+        if (dalloc(root, root->gatherAllocs, &root->gatherStage, needStage) || dalloc(root, root->gatherAllocs, &root->gatherFull, needFull)) return 1;
+        root->gatherStageFloats = needStage; root->gatherFullFloats = needFull;
+    }
+    return 0;
+}
+
+static int gatherFinish(flx_ctx *root, uint32_t nranks, float *out_host)
+{
+    const uint32_t npix = root->params.width * root->params.height;
+    launch_deinterleave(root->stream, root->gatherStage, root->gatherFull, npix, nranks, tilePixels(npix, 0, nranks));
+    LAUNCHED(root);
+    HIPCHK(root, hipMemcpyAsync(out_host, root->gatherFull, (size_t)npix * 16, hipMemcpyDeviceToHost, root->stream));
+    HIPCHK(root, hipStreamSynchronize(root->stream));
+    return 0;
+}
+
+// multi-process: every rank of the communicator calls this; out_host (width*height float4) is written on `root` only
+int flx_gather(flx_ctx *c, uint32_t root, float *out_host)
+{
+    MUTATES(c);
+    NEED(c, c->comm, "flx_gather: no group (flx_group_init first)");
+    NEED(c, c->fr.pixels && c->haveParams, "flx_gather: no framebuffer");
+    const uint32_t R = c->fr.nranks, me = c->fr.rank, npix = c->params.width * c->params.height;
+    NEED(c, root < R, "flx_gather: bad root");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (me != root) {
+        NCCLCHK(c, g_rccl.GroupStart());
+        NCCLCHK(c, g_rccl.Send(c->fr.pixels, (size_t)tilePixels(npix, me, R) * 4, ncclFloat32, (int)root, c->comm, c->stream));
+        NCCLCHK(c, g_rccl.GroupEnd());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    NEED(c, out_host, "flx_gather: null output on the root");
+    if (gatherBuffers(c, R)) return 1;
+    const size_t maxlp = tilePixels(npix, 0, R);
+    NCCLCHK(c, g_rccl.GroupStart());
+    for (uint32_t r = 0; r < R; r++) {
+        if (r == me) continue;
+        NCCLCHK(c, g_rccl.Recv(c->gatherStage + (size_t)r * maxlp * 4, (size_t)tilePixels(npix, r, R) * 4, ncclFloat32, (int)r, c->comm, c->stream));
+    }
+    NCCLCHK(c, g_rccl.GroupEnd());
+    HIPCHK(c, hipMemcpyAsync(c->gatherStage + (size_t)me * maxlp * 4, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
+    return gatherFinish(c, R, out_host);
+}
+
+// single process: the n contexts of flx_group_init_local, driven by one host thread
+int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
+{
+    if (!ctxs || !n || root >= n || !ctxs[root]) { g_create_error = "flx_gather_local: bad arguments"; return 1; }
+    flx_ctx *rc = ctxs[root];
+    NEED(rc, out_host, "flx_gather_local: null output");
+    for (uint32_t i = 0; i < n; i++) {
+        MUTATES(ctxs[i]);
+        NEED(rc, ctxs[i]->fr.nranks == n && ctxs[i]->fr.rank == i && ctxs[i]->fr.pixels && ctxs[i]->haveParams, "flx_gather_local: contexts are not the group of flx_group_init_local");
+        NEED(rc, (ctxs[i]->comm != nullptr) != ctxs[i]->commShared, "flx_gather_local: no group (flx_group_init_local first)");
+    }
+    HIPCHK(rc, hipSetDevice(rc->device));
+    if (gatherBuffers(rc, n)) return 1;
+    const uint32_t npix = rc->params.width * rc->params.height;
+    const size_t maxlp = tilePixels(npix, 0, n);
+    if (rc->comm) {
+        NCCLCHK(rc, g_rccl.GroupStart());
+        for (uint32_t r = 0; r < n; r++) {
+            if (r == root) continue;
+            HIPCHK(rc, hipSetDevice(ctxs[r]->device));
+            NCCLCHK(rc, g_rccl.Send(ctxs[r]->fr.pixels, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)root, ctxs[r]->comm, ctxs[r]->stream));
+            HIPCHK(rc, hipSetDevice(rc->device));
+            NCCLCHK(rc, g_rccl.Recv(rc->gatherStage + (size_t)r * maxlp * 4, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)r, rc->comm, rc->stream));
+        }
+        NCCLCHK(rc, g_rccl.GroupEnd());
+        for (uint32_t r = 0; r < n; r++) if (r != root) { HIPCHK(rc, hipSetDevice(ctxs[r]->device)); HIPCHK(rc, hipStreamSynchronize(ctxs[r]->stream)); }
+        HIPCHK(rc, hipSetDevice(rc->device));
+    } else {
+        for (uint32_t r = 0; r < n; r++) {
+            if (r == root) continue;
+            HIPCHK(rc, hipStreamSynchronize(ctxs[r]->stream));           // the tile is complete
+            HIPCHK(rc, hipMemcpyAsync(rc->gatherStage + (size_t)r * maxlp * 4, ctxs[r]->fr.pixels, (size_t)ctxs[r]->fr.localPixels * 16, hipMemcpyDeviceToDevice, rc->stream));
+        }
+    }
+    HIPCHK(rc, hipMemcpyAsync(rc->gatherStage + (size_t)root * maxlp * 4, rc->fr.pixels, (size_t)rc->fr.localPixels * 16, hipMemcpyDeviceToDevice, rc->stream));
+    return gatherFinish(rc, n, out_host);
 }
 
 // ---- measurement

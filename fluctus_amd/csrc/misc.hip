@@ -101,6 +101,20 @@ __global__ void k_bump_extension(uint32_t *counters, uint32_t srcMask)
         counters[FLX_Q_EXTENSION] += add;
     }
 }
+// multi-GPU gather, root side: rank r's tile holds its local pixels p = 0, 1, ... = global pixels p * nranks + r (flx_set_partition);
+// stage = nranks tiles of maxlp float4 each
+__global__ __launch_bounds__(MISC_BLOCK) void k_deinterleave(const float4 *stage, float4 *full, uint32_t npix, uint32_t nranks, uint32_t maxlp)
+{
+    const uint32_t g = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    if (g >= npix) return;
+    full[g] = stage[(size_t)(g % nranks) * maxlp + g / nranks];
+}
+void launch_deinterleave(hipStream_t s, const float *stage, float *full, uint32_t npix, uint32_t nranks, uint32_t maxlp)
+{
+    hipLaunchKernelGGL(k_deinterleave, dim3((npix + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s,
+                       reinterpret_cast<const float4 *>(stage), reinterpret_cast<float4 *>(full), npix, nranks, maxlp);
+}
+
 void launch_bump_extension(hipStream_t s, uint32_t *counters, uint32_t srcMask)
 {
     hipLaunchKernelGGL(k_bump_extension, dim3(1), dim3(64), 0, s, counters, srcMask);

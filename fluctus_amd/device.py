@@ -18,7 +18,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_wf_reset", "flx_wf_raygen", "flx_wf_extend", "flx_wf_shadow", "flx_wf_logic", "flx_wf_materials",
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
-           "flx_copy_pixels_to_device", "flx_stream", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
+           "flx_copy_pixels_to_device", "flx_stream", "flx_group_unique_id", "flx_group_init", "flx_group_init_local", "flx_gather", "flx_gather_local", "flx_group_destroy", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
@@ -164,6 +164,19 @@ class HipContext:
         self._chk(self.L.flx_read_pixels(self.h, which, _p(out)))
         return out
 
+    # multi-GPU group (RCCL); see include/fluctus_hip.h
+    def group_init(self, rank, nranks, unique_id):
+        """One process per GPU: ncclCommInitRank + the pixel partition.  unique_id: the 128 bytes of group_unique_id() made on rank 0."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.flx_group_init(self.h, C.c_uint32(rank), C.c_uint32(nranks), buf))
+
+    def gather(self, root=0):
+        """Collective over the group: returns the full (width*height, 4) accumulation image on `root`, None elsewhere."""
+        npix = int(self.params["width"]) * int(self.params["height"])
+        out = np.zeros((npix, 4), np.float32)
+        self._chk(self.L.flx_gather(self.h, C.c_uint32(root), _p(out)))
+        return out
+
     def copy_pixels_to_device(self, ptr):
         self._chk(self.L.flx_copy_pixels_to_device(self.h, C.c_void_p(ptr)))
 
@@ -227,3 +240,29 @@ class HipContext:
         return dict(ext={n: int(out[8 + i]) for i, n in enumerate(k)}, shadow={n: int(out[12 + i]) for i, n in enumerate(k)}, ext_max_inner_sum=int(out[7]))
 
     def set_option(self, name, value): self._chk(self.L.flx_set_option(self.h, name.encode(), int(value)))
+
+
+def group_unique_id():
+    """ncclGetUniqueId (rank 0 of a multi-process job); ship the bytes to the other ranks and pass them to HipContext.group_init."""
+    buf = (C.c_char * 128)()
+    if lib().flx_group_unique_id(buf) != 0:
+        raise RuntimeError("flx_group_unique_id failed: " + lib().flx_last_error(None).decode())
+    return bytes(buf)
+
+
+def _handles(ctxs):
+    return (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+
+
+def group_init_local(ctxs):
+    """Single process: contexts 0..n-1 become ranks 0..n-1 of one group (RCCL communicator if on distinct devices)."""
+    if lib().flx_group_init_local(_handles(ctxs), C.c_uint32(len(ctxs))) != 0:
+        raise RuntimeError("flx_group_init_local: " + lib().flx_last_error(ctxs[0].h).decode())
+
+
+def gather_local(ctxs, root=0):
+    p = ctxs[root].params
+    out = np.zeros((int(p["width"]) * int(p["height"]), 4), np.float32)
+    if lib().flx_gather_local(_handles(ctxs), C.c_uint32(len(ctxs)), C.c_uint32(root), _p(out)) != 0:
+        raise RuntimeError("flx_gather_local: " + lib().flx_last_error(ctxs[root].h).decode())
+    return out

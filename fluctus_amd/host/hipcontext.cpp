@@ -15,7 +15,7 @@ struct HipContext::Api {
     FN(flx_clear_queues) FN(flx_get_counters_async) FN(flx_finish) FN(flx_pixel_index_update) FN(flx_pixel_index_reset)
     FN(flx_num_tasks) FN(flx_postprocess) FN(flx_read_pixels) FN(flx_set_partition) FN(flx_local_pixels)
     FN(flx_mk_reset) FN(flx_mk_raygen) FN(flx_mk_next_vertex) FN(flx_mk_sample_bsdf) FN(flx_mk_splat) FN(flx_mk_splat_preview)
-    FN(flx_mk_stats_async) FN(flx_mk_stats_reset) FN(flx_set_option)
+    FN(flx_mk_stats_async) FN(flx_mk_stats_reset) FN(flx_set_option) FN(flx_group_init_local) FN(flx_gather_local)
 #undef FN
 };
 
@@ -42,7 +42,7 @@ HipContext::HipContext(int device, uint32_t numTasks, const std::string &libPath
     BIND(flx_clear_queues) BIND(flx_get_counters_async) BIND(flx_finish) BIND(flx_pixel_index_update) BIND(flx_pixel_index_reset)
     BIND(flx_num_tasks) BIND(flx_postprocess) BIND(flx_read_pixels) BIND(flx_set_partition) BIND(flx_local_pixels)
     BIND(flx_mk_reset) BIND(flx_mk_raygen) BIND(flx_mk_next_vertex) BIND(flx_mk_sample_bsdf) BIND(flx_mk_splat) BIND(flx_mk_splat_preview)
-    BIND(flx_mk_stats_async) BIND(flx_mk_stats_reset) BIND(flx_set_option)
+    BIND(flx_mk_stats_async) BIND(flx_mk_stats_reset) BIND(flx_set_option) BIND(flx_group_init_local) BIND(flx_gather_local)
 #undef BIND
     if (api->flx_create(device, numTasks, &ctx) != 0)
         throw std::runtime_error(std::string("HipContext: ") + api->flx_last_error(nullptr));
@@ -73,7 +73,7 @@ void HipContext::createEnvMap(EnvironmentMap *m)
 {
     check(api->flx_upload_envmap(ctx, m->getData(), m->getWidth(), m->getHeight(), m->getProbTable(), m->getAliasTable(), m->getPdfTable()), "createEnvMap");
 }
-void HipContext::updateParams(const RenderParams &p) { check(api->flx_set_params(ctx, &p), "updateParams"); }
+void HipContext::updateParams(const RenderParams &p) { check(api->flx_set_params(ctx, &p), "updateParams"); lastParams = p; }
 void HipContext::enqueueWfResetKernel(const RenderParams &) { check(api->flx_wf_reset(ctx), "wf_reset"); }
 void HipContext::enqueueWfRaygenKernel(const RenderParams &) { check(api->flx_wf_raygen(ctx), "wf_raygen"); }
 void HipContext::enqueueWfExtRayKernel(const RenderParams &) { check(api->flx_wf_extend(ctx), "wf_extension"); }
@@ -99,6 +99,20 @@ void HipContext::foldMkStats()
 }
 // The reference rebuilds every kernel with / without -DUSE_OPTIX_DENOISER; here the kernels branch on the presence of
 // the feature buffers, so "recompiling" is allocating or freeing them.
+// one process, one context per GPU: RCCL group + partitions 0..n-1 (flx_group_init_local), gather of the tiles on `root`
+void HipContext::groupInitLocal(const std::vector<HipContext *> &ranks)
+{
+    if (ranks.empty()) throw std::runtime_error("groupInitLocal: no contexts");
+    std::vector<flx_ctx *> h; for (auto *r : ranks) h.push_back(r->ctx);
+    ranks[0]->check(ranks[0]->api->flx_group_init_local(h.data(), (uint32_t)h.size()), "groupInitLocal");
+}
+void HipContext::gatherLocal(const std::vector<HipContext *> &ranks, uint32_t root, std::vector<float> &rgba)
+{
+    if (ranks.empty() || root >= ranks.size()) throw std::runtime_error("gatherLocal: bad arguments");
+    std::vector<flx_ctx *> h; for (auto *r : ranks) h.push_back(r->ctx);
+    rgba.resize((size_t)ranks[root]->lastParams.width * ranks[root]->lastParams.height * 4);
+    ranks[root]->check(ranks[root]->api->flx_gather_local(h.data(), (uint32_t)h.size(), root, rgba.data()), "gatherLocal");
+}
 void HipContext::setOption(const std::string &name, int value) { check(api->flx_set_option(ctx, name.c_str(), value), "setOption"); }
 void HipContext::recompileKernels(bool useDenoiser) { check(api->flx_set_option(ctx, "denoiser", useDenoiser ? 1 : 0), "recompileKernels"); }
 void HipContext::enqueueClearWfQueues() { check(api->flx_clear_queues(ctx), "clear queues"); }

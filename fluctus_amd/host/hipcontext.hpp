@@ -55,6 +55,10 @@ public:
     void resetPixelIndex();
     uint32_t getNumTasks() const;
     void setPartition(uint32_t rank, uint32_t nranks);
+    // multi-GPU from ONE process (no counterpart in the reference, one cl::CommandQueue): the contexts become ranks 0..n-1 of an RCCL
+    // group with the pixel-interleaved partition; gatherLocal collects the accumulation tiles on `root` (flx_group_init_local / flx_gather_local)
+    static void groupInitLocal(const std::vector<HipContext *> &ranks);
+    static void gatherLocal(const std::vector<HipContext *> &ranks, uint32_t root, std::vector<float> &rgba);
     uint32_t localPixels() const;
 
     // image export: raw accumulation (.pfm, float RGB = sum/count) or tonemapped preview (.ppm)
@@ -73,6 +77,7 @@ public:
 private:
     void check(int rc, const char *what);
     void foldMkStats();
+    RenderParams lastParams {};
     uint32_t mkStats[4] = {0, 0, 0, 0};
     bool mkPending = false;
     void *dl = nullptr;

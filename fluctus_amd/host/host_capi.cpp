@@ -138,6 +138,19 @@ int fh_envmap_get(void *e, float *rgb, float *prob, int *alias, float *pdf)
 #include "tracer.hpp"
 extern "C" {
 int fh_tracer_create(int width, int height, int device, uint32_t numTasks, void **out) { FH_TRY *out = new Tracer(width, height, device, numTasks); FH_CATCH }
+int fh_tracer_create_multi(int width, int height, const int *devices, int ndev, uint32_t numTasks, void **out)
+{
+    FH_TRY *out = new Tracer(width, height, std::vector<int>(devices, devices + ndev), numTasks); FH_CATCH
+}
+int fh_tracer_num_ranks(void *t) { return (int)((Tracer *)t)->numRanks(); }
+int fh_tracer_read_accumulation(void *t, float *out, uint64_t capFloats)
+{
+    FH_TRY
+    std::vector<float> px; ((Tracer *)t)->readAccumulation(px);
+    if (px.size() > capFloats) throw std::runtime_error("fh_tracer_read_accumulation: buffer too small");
+    memcpy(out, px.data(), px.size() * sizeof(float));
+    FH_CATCH
+}
 int fh_tracer_destroy(void *t) { delete (Tracer *)t; return 0; }
 int fh_tracer_init(void *t, int width, int height, const char *scene) { FH_TRY ((Tracer *)t)->init(width, height, scene); FH_CATCH }
 int fh_tracer_set_envmap(void *t, const char *hdr) { FH_TRY ((Tracer *)t)->setEnvMap(hdr); FH_CATCH }

@@ -23,7 +23,19 @@ Tracer::Tracer(int width, int height, int device, uint32_t numTasks)
     clctx.reset(new HipContext(device, numTasks));
 }
 
+Tracer::Tracer(int width, int height, const std::vector<int> &devices, uint32_t numTasks) : Tracer(width, height, devices.empty() ? 0 : devices[0], numTasks)
+{
+    for (size_t i = 1; i < devices.size(); i++) peers.emplace_back(new HipContext(devices[i], numTasks));
+    if (!peers.empty()) HipContext::groupInitLocal(ranks());
+}
+
 Tracer::~Tracer() { delete bvh; }
+
+void Tracer::readAccumulation(std::vector<float> &rgba)
+{
+    if (peers.empty()) { clctx->readPixels(0, rgba); return; }
+    HipContext::gatherLocal(ranks(), 0, rgba);
+}
 
 // reference: src/tracer.cpp:38-52
 void Tracer::resetParams(int width, int height)
@@ -86,7 +98,7 @@ void Tracer::init(int width, int height, const std::string &sceneFile)
     }
     initHierarchy();
     params.worldRadius = bvh->worldRadius();                 // :66-67
-    clctx->uploadSceneData(bvh, scene.get());
+    for (auto *c : ranks()) c->uploadSceneData(bvh, scene.get());    // replicated: read-only, 288 GB per GPU
     delete bvh; bvh = nullptr;                               // :72-73 data lives on the GPU now
     paramsUpdatePending = true;
     iteration = 0;
@@ -95,7 +107,7 @@ void Tracer::init(int width, int height, const std::string &sceneFile)
 void Tracer::setEnvMap(const std::string &hdrFile)
 {
     envMap.reset(new EnvironmentMap(hdrFile));
-    clctx->createEnvMap(envMap.get());
+    for (auto *c : ranks()) c->createEnvMap(envMap.get());
     params.useEnvMap = 1;
     paramsUpdatePending = true;
 }
@@ -141,6 +153,7 @@ bool Tracer::loadState()
 // reference: src/tracer.cpp:95-187
 void Tracer::renderSingle(int spp, bool denoise)
 {
+    if (!peers.empty()) throw std::runtime_error("renderSingle: the microkernel integrator is single-GPU");
     if (useWavefront) toggleRenderer();                                  // only MK guarantees the spp of every pixel (:99-101)
     if ((uint64_t)params.width * params.height > clctx->getNumTasks())
         throw std::runtime_error("renderSingle: width*height exceeds the context's numTasks (one path per pixel)");
@@ -185,42 +198,59 @@ void Tracer::updateMicrokernel()
     iteration++;
 }
 
-// reference: src/tracer.cpp:189-358
+// reference: src/tracer.cpp:189-358.  With several ranks every enqueue* call fans out over the devices (all asynchronous: one host
+// thread keeps them busy); each rank has its own counters and pixel cursor.
 void Tracer::update()
 {
-    if (paramsUpdatePending) { clctx->updateParams(params); paramsUpdatePending = false; iteration = 0; }
-    if (!useWavefront) { updateMicrokernel(); return; }
-    QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
+    auto R = ranks();
+    if (paramsUpdatePending) { for (auto *c : R) c->updateParams(params); paramsUpdatePending = false; iteration = 0; }
+    if (!useWavefront) {
+        if (!peers.empty()) throw std::runtime_error("update: the microkernel integrator is single-GPU");
+        updateMicrokernel(); return;
+    }
+    std::vector<QueueCounters> cnt(R.size());
+    std::memset(cnt.data(), 0, cnt.size() * sizeof(QueueCounters));
     uint32_t maxBounces = params.maxBounces;
     int N = 1;
     if (iteration == 0) {
         params.maxBounces = std::min((uint32_t)2, maxBounces);           // 2-bounce preview
-        clctx->updateParams(params);
         N = 3;
-        clctx->resetPixelIndex();
-        clctx->enqueueWfResetKernel(params);
-        clctx->enqueueWfRaygenKernel(params);
-        clctx->enqueueWfExtRayKernel(params);
-        clctx->enqueueClearWfQueues();
+        for (auto *c : R) {
+            c->updateParams(params);
+            c->resetPixelIndex();
+            c->enqueueWfResetKernel(params);
+            c->enqueueWfRaygenKernel(params);
+            c->enqueueWfExtRayKernel(params);
+            c->enqueueClearWfQueues();
+        }
     }
     for (int i = 0; i < N; i++) {
-        clctx->enqueueWfLogicKernel(params, iteration == 0);
-        clctx->enqueueWfRaygenKernel(params);
-        clctx->enqueueWfMaterialKernels(params);
-        clctx->enqueueGetCounters(&cnt);
-        clctx->enqueueWfExtRayKernel(params);
-        clctx->enqueueWfShadowRayKernel(params);
-        clctx->enqueueClearWfQueues();
+        for (size_t r = 0; r < R.size(); r++) {
+            HipContext *c = R[r];
+            c->enqueueWfLogicKernel(params, iteration == 0);
+            c->enqueueWfRaygenKernel(params);
+            c->enqueueWfMaterialKernels(params);
+            c->enqueueGetCounters(&cnt[r]);
+            c->enqueueWfExtRayKernel(params);
+            c->enqueueWfShadowRayKernel(params);
+            c->enqueueClearWfQueues();
+        }
     }
-    if (iteration == 0) { params.maxBounces = maxBounces; clctx->updateParams(params); }
-    clctx->enqueuePostprocessKernel(params);
-    clctx->finishQueue();
-    clctx->updatePixelIndex(clctx->localPixels(), cnt.raygenQueue);
-    clctx->statsAsync.extensionRays += cnt.extensionQueue;               // :336-339
-    clctx->statsAsync.shadowRays += cnt.shadowQueue;
-    clctx->statsAsync.primaryRays += cnt.raygenQueue;
-    clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
-    lastCnt = cnt;
+    if (iteration == 0) { params.maxBounces = maxBounces; for (auto *c : R) c->updateParams(params); }
+    for (auto *c : R) c->enqueuePostprocessKernel(params);
+    for (auto *c : R) c->finishQueue();
+    QueueCounters sum; std::memset(&sum, 0, sizeof(sum));
+    for (size_t r = 0; r < R.size(); r++) {
+        R[r]->updatePixelIndex(R[r]->localPixels(), cnt[r].raygenQueue);
+        sum.raygenQueue += cnt[r].raygenQueue; sum.extensionQueue += cnt[r].extensionQueue; sum.shadowQueue += cnt[r].shadowQueue;
+        sum.diffuseQueue += cnt[r].diffuseQueue; sum.glossyQueue += cnt[r].glossyQueue; sum.ggxReflQueue += cnt[r].ggxReflQueue;
+        sum.ggxRefrQueue += cnt[r].ggxRefrQueue; sum.deltaQueue += cnt[r].deltaQueue;
+    }
+    clctx->statsAsync.extensionRays += sum.extensionQueue;               // :336-339
+    clctx->statsAsync.shadowRays += sum.shadowQueue;
+    clctx->statsAsync.primaryRays += sum.raygenQueue;
+    clctx->statsAsync.samples += (iteration > 0) ? sum.raygenQueue : 0;
+    lastCnt = sum;
     iteration++;
 }
 
@@ -231,16 +261,20 @@ std::string Tracer::runBenchmark(double seconds, int iterations)
     auto now = [] { return std::chrono::duration<double>(clk::now().time_since_epoch()).count(); };
     std::ostringstream csv;
     csv << "scene;time;primary;extension;shadow;total;samples\n";
+    auto R = ranks();
+    if (!useWavefront && !peers.empty()) throw std::runtime_error("runBenchmark: the microkernel integrator is single-GPU");
     // resetRenderer (:372-382)
     iteration = 0;
-    clctx->updateParams(params); paramsUpdatePending = false;
-    clctx->resetPixelIndex();
-    clctx->enqueueWfResetKernel(params);
-    clctx->enqueueClearWfQueues();
-    clctx->enqueueResetKernel(params);                                   // :377
-    clctx->fetchStatsAsync();                                            // drains + zeroes the device-side MK counters
-    clctx->finishQueue();
-    clctx->resetStats();
+    paramsUpdatePending = false;
+    for (auto *c : R) {
+        c->updateParams(params);
+        c->resetPixelIndex();
+        c->enqueueWfResetKernel(params);
+        c->enqueueClearWfQueues();
+        if (peers.empty()) { c->enqueueResetKernel(params); c->fetchStatsAsync(); }   // :377; drains + zeroes the device-side MK counters
+        c->finishQueue();
+        c->resetStats();
+    }
     double startT = now(), lastLog = startT, currT = startT;
     int it = 0;
     auto log = [&](double t) {
@@ -249,33 +283,43 @@ std::string Tracer::runBenchmark(double seconds, int iterations)
         csv << sceneName << ";" << (t - startT) << ";" << s.primaryRays / sc << ";" << s.extensionRays / sc << ";" << s.shadowRays / sc << ";"
             << (s.primaryRays + s.extensionRays + s.shadowRays) / sc << ";" << s.samples / sc << "\n";
     };
+    std::vector<QueueCounters> cnt(R.size());
     while (iterations > 0 ? it < iterations : currT - startT < seconds) {
-        QueueCounters cnt; std::memset(&cnt, 0, sizeof(cnt));
-        if (useWavefront) {
-            clctx->enqueueWfLogicKernel(params, false);
-            clctx->enqueueWfRaygenKernel(params);
-            clctx->enqueueWfMaterialKernels(params);
-            clctx->enqueueGetCounters(&cnt);
-            clctx->enqueueWfExtRayKernel(params);
-            clctx->enqueueWfShadowRayKernel(params);
-            clctx->enqueueClearWfQueues();
-        } else {                                                         // :441-447
-            clctx->enqueueRayGenKernel(params);
-            clctx->enqueueNextVertexKernel(params);
-            clctx->enqueueBsdfSampleKernel(params);
-            clctx->enqueueSplatKernel(params);
-            clctx->fetchStatsAsync();
+        std::memset(cnt.data(), 0, cnt.size() * sizeof(QueueCounters));
+        for (size_t r = 0; r < R.size(); r++) {
+            HipContext *c = R[r];
+            if (useWavefront) {
+                c->enqueueWfLogicKernel(params, false);
+                c->enqueueWfRaygenKernel(params);
+                c->enqueueWfMaterialKernels(params);
+                c->enqueueGetCounters(&cnt[r]);
+                c->enqueueWfExtRayKernel(params);
+                c->enqueueWfShadowRayKernel(params);
+                c->enqueueClearWfQueues();
+            } else {                                                     // :441-447
+                c->enqueueRayGenKernel(params);
+                c->enqueueNextVertexKernel(params);
+                c->enqueueBsdfSampleKernel(params);
+                c->enqueueSplatKernel(params);
+                c->fetchStatsAsync();
+            }
+            c->enqueuePostprocessKernel(params);
         }
-        clctx->enqueuePostprocessKernel(params);
-        clctx->finishQueue();
-        if (useWavefront) {
-            clctx->statsAsync.extensionRays += cnt.extensionQueue;
-            clctx->statsAsync.shadowRays += cnt.shadowQueue;
-            clctx->statsAsync.primaryRays += cnt.raygenQueue;
-            clctx->statsAsync.samples += (iteration > 0) ? cnt.raygenQueue : 0;
+        for (auto *c : R) c->finishQueue();
+        QueueCounters sum; std::memset(&sum, 0, sizeof(sum));
+        for (size_t r = 0; r < R.size(); r++) {
+            if (useWavefront) {
+                clctx->statsAsync.extensionRays += cnt[r].extensionQueue;
+                clctx->statsAsync.shadowRays += cnt[r].shadowQueue;
+                clctx->statsAsync.primaryRays += cnt[r].raygenQueue;
+                clctx->statsAsync.samples += (iteration > 0) ? cnt[r].raygenQueue : 0;
+            }
+            R[r]->updatePixelIndex(R[r]->localPixels(), cnt[r].raygenQueue);
+            sum.raygenQueue += cnt[r].raygenQueue; sum.extensionQueue += cnt[r].extensionQueue; sum.shadowQueue += cnt[r].shadowQueue;
+            sum.diffuseQueue += cnt[r].diffuseQueue; sum.glossyQueue += cnt[r].glossyQueue; sum.ggxReflQueue += cnt[r].ggxReflQueue;
+            sum.ggxRefrQueue += cnt[r].ggxRefrQueue; sum.deltaQueue += cnt[r].deltaQueue;
         }
-        clctx->updatePixelIndex(clctx->localPixels(), cnt.raygenQueue);
-        lastCnt = cnt;
+        lastCnt = sum;
         iteration++; it++;
         currT = now();
         if (currT - lastLog > 0.5) log(currT);

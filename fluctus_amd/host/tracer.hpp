@@ -8,6 +8,7 @@
 #pragma once
 #include <memory>
 #include <string>
+#include <vector>
 #include "hipcontext.hpp"
 
 namespace fluctus {
@@ -15,6 +16,13 @@ namespace fluctus {
 class Tracer {
 public:
     Tracer(int width, int height, int device = 0, uint32_t numTasks = 1u << 20);
+    // one process driving several GPUs of a node: devices[0] is the root; every device runs the complete wavefront loop
+    // on its own interleaved pixel subset with its own numTasks paths, scene replicated; tiles are gathered over RCCL for read-back.
+    // The same device may be listed more than once (1-GPU stand-in for N ranks).
+    Tracer(int width, int height, const std::vector<int> &devices, uint32_t numTasks);
+    uint32_t numRanks() const { return 1u + (uint32_t)peers.size(); }
+    // full-resolution accumulation image (rgb sum, sample count) assembled from all ranks
+    void readAccumulation(std::vector<float> &rgba);
     ~Tracer();
 
     void init(int width, int height, const std::string &sceneFile);             // file path or "proc:<kind>:<tris>:<seed>"
@@ -26,7 +34,7 @@ public:
     // final-frame render: exactly `spp` samples in every pixel (reference: src/tracer.cpp:95-187).  Switches to the
     // microkernel integrator and turns Russian roulette off, as the reference does; needs numTasks >= width*height.
     void renderSingle(int spp, bool denoise = false);                             // denoise: also fill the denoiser feature buffers
-    void setDenoiser(bool on) { useDenoiser = on; clctx->recompileKernels(on); iteration = 0; }
+    void setDenoiser(bool on) { useDenoiser = on; for (auto *c : ranks()) c->recompileKernels(on); iteration = 0; }
     void toggleRenderer() { useWavefront = !useWavefront; iteration = 0; }        // src/tracer.cpp:881-886
     bool usesWavefront() const { return useWavefront; }
     void saveImage(const std::string &filename) { clctx->saveImage(filename, params); }
@@ -58,7 +66,9 @@ private:
     RenderParams params;
     std::unique_ptr<Scene> scene;
     std::unique_ptr<EnvironmentMap> envMap;
-    std::unique_ptr<HipContext> clctx;
+    std::unique_ptr<HipContext> clctx;                                            // rank 0
+    std::vector<std::unique_ptr<HipContext>> peers;                               // ranks 1..R-1 (multi-GPU wavefront path)
+    std::vector<HipContext *> ranks() { std::vector<HipContext *> r{clctx.get()}; for (auto &p : peers) r.push_back(p.get()); return r; }
     BVH *bvh = nullptr;
     uint32_t iteration = 0;
     bool paramsUpdatePending = true;

@@ -7,9 +7,26 @@ from .wire import RENDER_PARAMS
 
 class Tracer:
     def __init__(self, width, height, device=0, num_tasks=1 << 20):
+        """device: one HIP device index, or a list of them (one process driving several GPUs: devices[0] is the root; the same
+        index may repeat -- a 1-GPU stand-in for N ranks)."""
         self.L = host.lib()
         self.h = C.c_void_p()
-        host._chk(self.L.fh_tracer_create(int(width), int(height), int(device), C.c_uint32(num_tasks), C.byref(self.h)))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            host._chk(self.L.fh_tracer_create_multi(int(width), int(height), devs, len(device), C.c_uint32(num_tasks), C.byref(self.h)))
+        else:
+            host._chk(self.L.fh_tracer_create(int(width), int(height), int(device), C.c_uint32(num_tasks), C.byref(self.h)))
+
+    @property
+    def num_ranks(self):
+        return int(self.L.fh_tracer_num_ranks(self.h))
+
+    def read_accumulation(self):
+        """Full-resolution accumulation image (rgb sum, sample count), gathered from all ranks."""
+        p = self.params
+        out = np.zeros((int(p["width"]) * int(p["height"]), 4), np.float32)
+        host._chk(self.L.fh_tracer_read_accumulation(self.h, out.ctypes.data_as(C.c_void_p), C.c_uint64(out.size)))
+        return out
 
     def close(self):
         if self.h:

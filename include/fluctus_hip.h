@@ -121,6 +121,26 @@ int flx_copy_pixels_to_device(flx_ctx *ctx, void *dst_device_ptr);
 /* the context's hipStream_t, for callers that order their own work after ours */
 void *flx_stream(flx_ctx *ctx);
 
+/* ---- multi-GPU group and gather over RCCL / xGMI (SURVEY 8(b) flx_create_group / flx_gather, 8(e)).  librccl.so.1 is bound with
+ * dlopen at the first call, so single-GPU users never load it.  Two ways to form the group:
+ *   one process per GPU (torchrun / MPI style): rank 0 calls flx_group_unique_id and ships the 128 bytes to the other ranks by
+ *     whatever channel the launcher has; every rank then calls flx_group_init(ctx, rank, nranks, id) (= ncclCommInitRank +
+ *     flx_set_partition), renders, and all ranks call flx_gather(ctx, root, out) -- a collective; `out` (width*height float4,
+ *     host) is written on the root only.
+ *   one process, N contexts on N devices (the reference's single-process Tracer driving a node): flx_group_init_local(ctxs, n)
+ *     (= ncclCommInitAll + partitions 0..n-1) and flx_gather_local(ctxs, n, root, out).  If several of the contexts sit on the SAME
+ *     device (a 1-GPU box standing in for N ranks) the tiles travel by device-to-device copies instead of RCCL, everything else
+ *     (partition, staging, de-interleave) is the same code.
+ * Each rank sends its compact float4[local pixels] accumulation tile (rgb sum, sample count) point-to-point to the root
+ * (grouped ncclSend / ncclRecv); the root de-interleaves global pixel p*R + r <- tile r, pixel p.  Blocking. */
+#define FLX_GROUP_ID_BYTES 128
+int flx_group_unique_id(void *out128);
+int flx_group_init(flx_ctx *ctx, uint32_t rank, uint32_t nranks, const void *id128);
+int flx_group_init_local(flx_ctx **ctxs, uint32_t n);
+int flx_gather(flx_ctx *ctx, uint32_t root, float *out_rgba_host);
+int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_rgba_host);
+int flx_group_destroy(flx_ctx *ctx);
+
 /* ---- measurement.  Per-kernel HIP-event timing on the context's stream (the reference attaches
  * cl::Events to the two trace kernels, src/clcontext.cpp:673-701,780,786).  kernel ids: */
 enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FLX_K_LOGIC = 4, FLX_K_MATERIALS = 5,

@@ -10,11 +10,13 @@ def find(sub, pat):
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_extend", "k_shadow", "k_logic", "k_material", "k_raygen", "k_reset", "k_queue_scan", "k_queue_scatter",
+    for k in ("k_extend4", "k_shadow4", "k_extend", "k_shadow", "k_logic", "k_material", "k_raygen", "k_reset", "k_queue_scan", "k_queue_scatter",
               "k_end_iteration", "k_postprocess", "k_state"):
         if k in n:
             if k == "k_material":
                 return n[n.find("k_material"):][:24]
+            if k in ("k_extend4", "k_shadow4", "k_extend", "k_shadow"):
+                return k + ("<STATS>" if "<true>" in name or "ILb1E" in name else "")
             return k
     return n[:40]
 

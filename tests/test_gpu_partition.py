@@ -134,3 +134,64 @@ def test_bench_rccl_path_single_rank(tmp_path):
     assert j["n_gpus"] == 1 and j["value"] > 0
     assert "gather_ms" in j and j["gather_ms"] > 0
     assert j["gather_matches_read_pixels"] is True
+    assert j["gather_native_matches_torch"] is True and j["gather_ms_native_rccl"] > 0     # flx_group_init + flx_gather beside torch's
+
+
+@pytest.mark.parametrize("nranks,root", [(3, 0), (4, 2), (8, 7)])
+def test_native_gather_local_group_on_one_device(nranks, root):
+    """flx_group_init_local / flx_gather_local with N contexts on the ONE device of this box (tiles travel by device copies, RCCL
+    refuses duplicate devices): every rank free-runs its partition, the gathered image must be exactly the interleave of the
+    ranks' own framebuffers, and the whole must conserve the splat count."""
+    from fluctus_amd import device
+    d = common.mixed_material_scene()
+    w, h, n = 75, 41, 4096                       # 3075 pixels: ragged for 4 and 8 ranks
+    p = common.scene_params(d, w, h, maxBounces=4, useAreaLight=1, wfSeparateQueues=1)
+    ctxs = []
+    for r in range(nranks):
+        g = device.HipContext(n)
+        g.upload_scene(d); g.set_params(p)
+        ctxs.append(g)
+    device.group_init_local(ctxs)
+    new = 0
+    for r, g in enumerate(ctxs):
+        assert g.local_pixels() == multi.local_pixel_count(w * h, r, nranks)
+        driver.reset_renderer(g)
+        for it in range(12):
+            cnt = driver.benchmark_iteration(g, g.local_pixels())
+            if it > 0:
+                new += int(cnt[Q.RAYGEN])
+    full = device.gather_local(ctxs, root)
+    assert full.shape == (w * h, 4) and np.isfinite(full).all()
+    for r, g in enumerate(ctxs):
+        assert np.array_equal(full[r::nranks], g.read_pixels(0)), f"rank {r}'s tile is not at global pixels {r}, {r}+{nranks}, ..."
+    assert int(full[:, 3].sum()) == new
+    # a second gather (buffers reused) gives the same image
+    assert np.array_equal(device.gather_local(ctxs, root), full)
+
+
+def test_native_gather_over_rccl_single_rank():
+    """The RCCL path proper on the one GPU there is: ncclGetUniqueId -> ncclCommInitRank(nranks = 1) -> flx_gather, and the
+    single-process flavour ncclCommInitAll(1).  (N > 1 over xGMI is the driver's 8-GPU run: bench.py uses flx_gather there and
+    checks it against torch.distributed's gather.)"""
+    from fluctus_amd import device
+    d = common.simple_scene()
+    w, h, n = 40, 30, 2048
+    p = common.scene_params(d, w, h, maxBounces=4)
+    g = device.HipContext(n)
+    g.upload_scene(d); g.set_params(p)
+    g.group_init(0, 1, device.group_unique_id())
+    driver.reset_renderer(g)
+    for _ in range(8):
+        driver.benchmark_iteration(g, w * h)
+    full = g.gather(0)
+    assert np.array_equal(full, g.read_pixels(0)) and full[:, 3].sum() > 0
+    g2 = device.HipContext(n)
+    g2.upload_scene(d); g2.set_params(p)
+    device.group_init_local([g2])
+    driver.reset_renderer(g2)
+    for _ in range(8):
+        driver.benchmark_iteration(g2, w * h)
+    assert np.array_equal(device.gather_local([g2], 0), g2.read_pixels(0))
+    # same scene, same seeds: the same render (sums up to the order of the float atomics of paths sharing a pixel)
+    again = device.gather_local([g2], 0)
+    assert np.array_equal(again[:, 3], full[:, 3]) and np.allclose(again, full, rtol=1e-6, atol=1e-7)
