@@ -110,10 +110,11 @@ def decode_jpeg(data):
 BVH_MODES = {"sbvh": 0, "sah": 1, "binned": 2}
 
 
-def build_bvh(d, mode="sbvh"):
+def build_bvh(d, mode="sbvh", threads=0, job_size=0):
+    """threads: 0 = all usable cores (the SBVH builder is parallel; the tree does not depend on the thread count), 1 = serial."""
     L = lib()
     h = C.c_void_p()
-    _chk(L.fh_bvh_build(_p(d.tris), C.c_uint64(d.tris.size), BVH_MODES[mode], C.byref(h)))
+    _chk(L.fh_bvh_build_ex(_p(d.tris), C.c_uint64(d.tris.size), BVH_MODES[mode], int(threads), C.c_uint64(job_size), C.byref(h)))
     try:
         nn, ni = C.c_uint64(), C.c_uint64()
         met = (C.c_uint32 * 4)()

@@ -7,6 +7,10 @@
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
+#include <parallel/algorithm>      // __gnu_parallel::sort (OpenMP); a strict total order makes its result the serial one
+#include <omp.h>
+#include <sched.h>
+#include <cstdio>
 
 namespace fluctus {
 
@@ -22,12 +26,17 @@ Box triBox(const flx_triangle &t)
 }
 
 // sort key = box.min[d] + box.max[d], ties by triangle index (reference: src/bvh.cpp:258-272)
-void sortRefs(std::vector<Ref> &refs, size_t s, size_t e /*inclusive*/, int dim)
+// `par`: the caller is the only running thread (top of the tree): sort with all cores.  Triangle indices are unique within a node
+// (a split triangle's halves go to different children), so (key, ind) is a strict total order and every sorting algorithm, serial
+// or parallel, produces the same array.
+void sortRefs(std::vector<Ref> &refs, size_t s, size_t e /*inclusive*/, int dim, bool par = false)
 {
-    std::sort(refs.begin() + s, refs.begin() + e + 1, [dim](const Ref &a, const Ref &b) {
+    auto less = [dim](const Ref &a, const Ref &b) {
         float ca = a.box.mn[dim] + a.box.mx[dim], cb = b.box.mn[dim] + b.box.mx[dim];
         return ca < cb || (ca == cb && a.ind < b.ind);
-    });
+    };
+    if (par && e - s > 50000) __gnu_parallel::sort(refs.begin() + s, refs.begin() + e + 1, less);
+    else std::sort(refs.begin() + s, refs.begin() + e + 1, less);
 }
 
 struct Split { int i = -1; float pos = 0; int dim = -1; float cost = FLT_MAX; Box left, right; };
@@ -56,6 +65,7 @@ struct SbvhBuilder {
     std::vector<Bin> bins;                // 3 * Bins
 
     struct Spec { int refs = 0; Box box; };
+    bool par = false;                     // this builder works on a top-of-tree node with all cores (parallel sort / binning)
 
     explicit SbvhBuilder(const std::vector<flx_triangle> &t) : tris(t), bins(3 * Bins) {}
 
@@ -75,7 +85,7 @@ struct SbvhBuilder {
         Split best; float bestTie = FLT_MAX;
         size_t start = refs.size() - s.refs, end = refs.size() - 1;
         for (int dim = 0; dim < 3; dim++) {
-            sortRefs(refs, start, end, dim);
+            sortRefs(refs, start, end, dim, par);
             Box rb;
             for (int i = s.refs - 1; i > 0; i--) { rb.expand(refs[start + i].box); rightBoxes[i - 1] = rb; }
             Box lb;
@@ -126,25 +136,40 @@ struct SbvhBuilder {
         float origin[3], binSize[3], inv[3];
         for (int k = 0; k < 3; k++) { origin[k] = s.box.mn[k]; binSize[k] = (s.box.mx[k] - origin[k]) * (1.0f / (float)Bins); inv[k] = 1.0f / binSize[k]; }
         for (auto &b : bins) { b.bounds = Box(); b.enter = b.exit = 0; }
-        for (size_t r = refs.size() - s.refs; r < refs.size(); r++) {
-            const Ref &ref = refs[r];
-            for (int dim = 0; dim < 3; dim++) {
-                int first = toBin((ref.box.mn[dim] - origin[dim]) * inv[dim]);
-                int last = toBin((ref.box.mx[dim] - origin[dim]) * inv[dim]);
-                if (last < first) last = first;
-                Ref cur = ref;
-                for (int i = first; i < last; i++) {
-                    Ref l, rr;
-                    float coord = origin[dim] + binSize[dim] * (float)(i + 1);
-                    splitReference(l, rr, cur, dim, coord);
-                    bins[dim * Bins + i].bounds.expand(l.box);
-                    cur = rr;
+        auto accumulate = [&](std::vector<Bin> &into, size_t r0, size_t r1) {
+            for (size_t r = r0; r < r1; r++) {
+                const Ref &ref = refs[r];
+                for (int dim = 0; dim < 3; dim++) {
+                    int first = toBin((ref.box.mn[dim] - origin[dim]) * inv[dim]);
+                    int last = toBin((ref.box.mx[dim] - origin[dim]) * inv[dim]);
+                    if (last < first) last = first;
+                    Ref cur = ref;
+                    for (int i = first; i < last; i++) {
+                        Ref l, rr;
+                        float coord = origin[dim] + binSize[dim] * (float)(i + 1);
+                        splitReference(l, rr, cur, dim, coord);
+                        into[dim * Bins + i].bounds.expand(l.box);
+                        cur = rr;
+                    }
+                    into[dim * Bins + last].bounds.expand(cur.box);
+                    into[dim * Bins + first].enter++;
+                    into[dim * Bins + last].exit++;
                 }
-                bins[dim * Bins + last].bounds.expand(cur.box);
-                bins[dim * Bins + first].enter++;
-                bins[dim * Bins + last].exit++;
             }
-        }
+        };
+        const size_t r0 = refs.size() - s.refs, r1 = refs.size();
+        if (par && s.refs > 50000) {
+            // per-thread bins merged with min / max / integer sums: the same bins in any order
+            #pragma omp parallel
+            {
+                std::vector<Bin> local(3 * Bins);
+                const int nt = omp_get_num_threads(), t = omp_get_thread_num();
+                const size_t chunk = (r1 - r0 + nt - 1) / nt, a = r0 + (size_t)t * chunk, b = std::min(r1, a + chunk);
+                if (a < b) accumulate(local, a, b);
+                #pragma omp critical
+                for (int i = 0; i < 3 * Bins; i++) { bins[i].bounds.expand(local[i].bounds); bins[i].enter += local[i].enter; bins[i].exit += local[i].exit; }
+            }
+        } else accumulate(bins, r0, r1);
         Split sp;
         for (int dim = 0; dim < 3; dim++) {
             Box rb;
@@ -164,7 +189,7 @@ struct SbvhBuilder {
     // reference: src/sbvh.cpp:225-241
     void partitionObject(Spec &L, Spec &R, const Spec &s, const Split &sp)
     {
-        sortRefs(refs, refs.size() - s.refs, refs.size() - 1, sp.dim);
+        sortRefs(refs, refs.size() - s.refs, refs.size() - 1, sp.dim, par);
         L.refs = sp.i; L.box = sp.left; R.refs = s.refs - sp.i; R.box = sp.right;
     }
 
@@ -222,6 +247,80 @@ struct SbvhBuilder {
         TreeNode n; n.box = s.box; n.left = ln; n.right = rn;
         tree.push_back(n);
         return (int)tree.size() - 1;
+    }
+
+    // ---- parallel build.  A node's subtree depends only on its SET of references (every decision sorts them first), so subtrees
+    // are independent: the top of the tree -- nodes with more than `big` references -- is split one node after the other with all
+    // cores inside each split (parallel sort + binning); every smaller node becomes a JOB, built serially by a private builder, all
+    // jobs in parallel.  Same decisions on the same data as the serial recursion, hence the same tree (tests/test_host.py).
+    struct Job { std::vector<Ref> refs; Spec spec; int depth; int node; };   // node: placeholder in `tree` to be replaced by the job's root
+    std::vector<Job> jobs;
+
+    int buildTop(Spec &s, int depth, size_t big)
+    {
+        depthMax = std::max(depthMax, (uint32_t)depth);
+        if ((size_t)s.refs <= big || s.refs <= MinLeaf || depth >= MaxDepth) {
+            Job j; j.spec = s; j.depth = depth;
+            j.refs.assign(refs.end() - s.refs, refs.end());
+            refs.resize(refs.size() - s.refs);
+            tree.push_back(TreeNode()); j.node = (int)tree.size() - 1;
+            jobs.push_back(std::move(j));
+            return jobs.back().node;
+        }
+        par = true;
+        float parentArea = s.box.area();
+        float nodeSAH = parentArea * 2 * 1;
+        Split obj = sahSplit(s, nodeSAH);
+        Split spatial;
+        if (depth < MaxSpatialDepth) {
+            Box ov = obj.left; ov.intersect(obj.right);
+            if (ov.area() >= minOverlap) spatial = binSplit(s, nodeSAH);
+        }
+        float parentCost = parentArea * (float)s.refs;
+        float minCost = std::min(obj.cost, std::min(spatial.cost, parentCost));
+        if (minCost == parentCost && s.refs <= MaxLeaf) { par = false; return leaf(s); }
+        Spec L, R;
+        if (minCost == spatial.cost) { partitionSpatial(L, R, s, spatial); if (L.refs && R.refs) spatialSplits++; }
+        if (!L.refs || !R.refs) partitionObject(L, R, s, obj);
+        par = false;
+        splits++;
+        duplicates += (uint32_t)(L.refs + R.refs - s.refs);
+        int rn = buildTop(R, depth + 1, big);
+        int ln = buildTop(L, depth + 1, big);
+        TreeNode n; n.box = s.box; n.left = ln; n.right = rn;
+        tree.push_back(n);
+        return (int)tree.size() - 1;
+    }
+
+    // build every job with a private serial builder, then graft the subtrees into `tree` / `leafInd`
+    void runJobs()
+    {
+        struct Done { std::vector<TreeNode> tree; std::vector<uint32_t> leafInd; int root; uint32_t depthMax, splits, duplicates, spatialSplits; };
+        std::vector<Done> done(jobs.size());
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (size_t k = 0; k < jobs.size(); k++) {
+            SbvhBuilder b(tris);
+            b.minOverlap = minOverlap;
+            b.refs = std::move(jobs[k].refs);
+            b.rightBoxes.resize(std::max(b.refs.size(), (size_t)Bins));
+            Spec sp = jobs[k].spec;
+            Done &d = done[k];
+            d.root = b.build(sp, jobs[k].depth);
+            d.tree = std::move(b.tree); d.leafInd = std::move(b.leafInd);
+            d.depthMax = b.depthMax; d.splits = b.splits; d.duplicates = b.duplicates; d.spatialSplits = b.spatialSplits;
+        }
+        for (size_t k = 0; k < jobs.size(); k++) {
+            Done &d = done[k];
+            const int toff = (int)tree.size(); const uint32_t loff = (uint32_t)leafInd.size();
+            for (TreeNode n : d.tree) {
+                if (n.left >= 0) { n.left += toff; n.right += toff; } else n.leafStart += loff;
+                tree.push_back(n);
+            }
+            leafInd.insert(leafInd.end(), d.leafInd.begin(), d.leafInd.end());
+            tree[jobs[k].node] = tree[toff + d.root];            // the placeholder becomes (a copy of) the job's root node
+            depthMax = std::max(depthMax, d.depthMax); splits += d.splits; duplicates += d.duplicates; spatialSplits += d.spatialSplits;
+        }
+        jobs.clear();
     }
 
     // DFS, left child = next slot (reference: src/sbvh.cpp:52-73)
@@ -320,6 +419,22 @@ struct ObjBuilder {
 
 } // namespace
 
+int BVH::usableThreads()
+{
+    int n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32]; long period = 0;
+        if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && quota[0] != 'm' && period > 0) {
+            long q = std::atol(quota) / period;
+            if (q >= 1 && q < n) n = (int)q;
+        }
+        std::fclose(f);
+    }
+    return n < 1 ? 1 : n;
+}
+
 void BVH::build(const std::vector<flx_triangle> *tris, Mode mode)
 {
     m_tris = tris;
@@ -333,7 +448,17 @@ void BVH::build(const std::vector<flx_triangle> *tris, Mode mode)
         for (size_t i = 0; i < n; i++) { b.refs[i].ind = (uint32_t)i; b.refs[i].box = triBox((*tris)[i]); root.box.expand(b.refs[i].box); }
         b.rightBoxes.resize(std::max(n, (size_t)SbvhBuilder::Bins));
         b.minOverlap = root.box.area() * 1e-5f;           // splitAlpha (src/sbvh.hpp:70)
-        int r = b.build(root, 0);
+        int r;
+        const int threads = sbvhThreads > 0 ? sbvhThreads : usableThreads();
+        if (threads <= 1) r = b.build(root, 0);           // the reference's serial recursion
+        else {
+            const int before = omp_get_max_threads();
+            omp_set_num_threads(threads);
+            const size_t big = sbvhJobSize > 0 ? sbvhJobSize : std::max((size_t)4096, n / (size_t)(8 * threads));
+            r = b.buildTop(root, 0, big);
+            b.runJobs();
+            omp_set_num_threads(before);
+        }
         b.emit(r, -1, m_nodes, m_indices);
         metrics.depth = b.depthMax; metrics.splits = b.splits; metrics.duplicates = b.duplicates; metrics.spatialSplits = b.spatialSplits;
     } else {

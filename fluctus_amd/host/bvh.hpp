@@ -50,6 +50,13 @@ public:
     void getSceneBounds(float mn[3], float mx[3]) const;   // reference: src/bvh.cpp:53-59
     float worldRadius() const;                             // 0.5*|max-min| (src/tracer.cpp:66-67)
 
+    // SBVH build parallelism: threads 0 = all OpenMP threads, 1 = the serial recursion; job size 0 = n / (8 * threads) references.
+    // The tree does not depend on either (tests/test_host.py::test_sbvh_parallel_build_is_the_serial_tree).
+    int sbvhThreads = 0;
+    size_t sbvhJobSize = 0;
+    // cores this process may really use: affinity mask capped by the cgroup v2 CPU quota (a container can show 256 CPUs and grant 16)
+    static int usableThreads();
+
     std::vector<flx_node> m_nodes;
     std::vector<uint32_t> m_indices;
     struct { uint32_t depth = 0, splits = 0, duplicates = 0, spatialSplits = 0; } metrics;

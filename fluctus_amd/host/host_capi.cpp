@@ -89,6 +89,20 @@ int fh_bvh_build(const void *tris, uint64_t ntris, int mode, void **out)
     *out = b;
     FH_CATCH
 }
+// threads: 0 = every core this process may use (affinity capped by the cgroup CPU quota), 1 = the serial recursion; jobSize 0 = default
+int fh_bvh_build_ex(const void *tris, uint64_t ntris, int mode, int threads, uint64_t jobSize, void **out)
+{
+    FH_TRY
+    std::vector<flx_triangle> *copy = new std::vector<flx_triangle>((const flx_triangle *)tris, (const flx_triangle *)tris + ntris);
+    BVH *b = new BVH();
+    b->sbvhThreads = threads; b->sbvhJobSize = (size_t)jobSize;
+    try { b->build(copy, mode == 0 ? BVH::Mode::SBVH : mode == 1 ? BVH::Mode::SAH : BVH::Mode::Binned); }
+    catch (...) { delete copy; delete b; throw; }
+    delete copy;
+    *out = b;
+    FH_CATCH
+}
+int fh_usable_threads() { return BVH::usableThreads(); }
 int fh_bvh_destroy(void *b) { delete (BVH *)b; return 0; }
 int fh_bvh_counts(void *b, uint64_t *nnodes, uint64_t *nidx, uint32_t *metrics4)
 {

@@ -63,8 +63,10 @@ def steps(tag, denoiser=False, **flags):
     if denoiser:
         c.set_option("denoiser", 1)                                         # the -DUSE_OPTIX_DENOISER builds of logic / process
     c.upload_scene(d); c.upload_envmap(e); c.set_params(p); driver.reset_renderer(c)
+    cursor = 0                                                              # the reference's host-side pixel cursor (src/clcontext.cpp:891-895)
     for _ in range(6):
-        driver.benchmark_iteration(c, w * h)
+        cursor = (cursor + int(driver.benchmark_iteration(c, w * h)[0])) % (w * h)
+    cursors = [cursor]
     _snap = snapshot
     snapshot_ = lambda ctx: _snap(ctx, aov=denoiser)
     snaps, names = [snapshot_(c)], ["start"]
@@ -72,16 +74,17 @@ def steps(tag, denoiser=False, **flags):
         for name, fn in (("logic", lambda: c.wf_logic(False)), ("raygen", c.wf_raygen), ("materials", c.wf_materials),
                          ("extend", c.wf_extend), ("shadow", c.wf_shadow)):
             fn()
-            snaps.append(snapshot_(c)); names.append(name)
+            snaps.append(snapshot_(c)); names.append(name); cursors.append(cursor)
         cnt = c.get_counters().copy()
         c.clear_queues(); c.pixel_index_update(w * h, int(cnt[0]))
-        snaps.append(snapshot_(c)); names.append("end")
+        cursor = (cursor + int(cnt[0])) % (w * h)
+        snaps.append(snapshot_(c)); names.append("end"); cursors.append(cursor)
     extra = dict(aov=np.stack([s["aov"] for s in snaps])) if denoiser else {}
     np.savez_compressed(os.path.join(OUT, f"steps_{tag}.npz"), num_tasks=n, **extra, params=np.asarray(p).reshape(1).view(np.uint8),
                         names=np.array(names), states=np.stack([s["state"] for s in snaps]),
                         counters=np.stack([s["counters"] for s in snaps]), queues=np.stack([s["queues"] for s in snaps]),
                         env_rgb=e.rgb, env_prob=e.prob, env_alias=e.alias, env_pdf=e.pdf, env_wh=np.array([e.w, e.h]),
-                        pixel_cursor_start=np.array([0]), **scene_arrays(d))
+                        pixel_cursor=np.array(cursors, np.uint32), **scene_arrays(d))      # cursor in effect when snapshot k was taken
     print(f"steps_{tag}.npz", names)
 
 
@@ -97,6 +100,32 @@ def raygen():
     np.savez_compressed(os.path.join(OUT, "raygen.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8), state=st,
                         ext_queue=c.queue_read(1), counters=c.get_counters().copy())
     print("raygen.npz")
+
+
+def teapot_resync():
+    """BASELINE.json configs[0] geometry (teapot.ply, Lambertian, area light, 4 bounces) on the wavefront path, 64x64, 4096 paths:
+    the reference's full state BEFORE each of 12 consecutive iterations + the framebuffer after each.  A test restarts every
+    iteration from the reference's state, so hit-index flips cannot fork the runs and every iteration is compared exactly."""
+    d = host.load_scene("/root/reference/assets/teapot.ply")
+    host.build_bvh(d, "sbvh")
+    w = h = 64
+    n = 4096
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    p["maxBounces"] = 4
+    c = RefContext(n)
+    c.upload_scene(d); c.set_params(p); driver.reset_renderer(c)
+    cursor = 0
+    for _ in range(4):                                                      # past the all-primary start
+        cursor = (cursor + int(driver.benchmark_iteration(c, w * h)[0])) % (w * h)
+    states, cursors, pixels, counters = [c.state_export()], [cursor], [c.read_pixels(0)], []
+    for _ in range(12):
+        cnt = driver.benchmark_iteration(c, w * h)
+        cursor = (cursor + int(cnt[0])) % (w * h)
+        counters.append(cnt); states.append(c.state_export()); cursors.append(cursor); pixels.append(c.read_pixels(0))
+    np.savez_compressed(os.path.join(OUT, "teapot_resync.npz"), num_tasks=n, params=np.asarray(p).reshape(1).view(np.uint8),
+                        states=np.stack(states), pixel_cursor=np.array(cursors, np.uint32), pixels=np.stack(pixels),
+                        counters=np.stack(counters), **scene_arrays(d))
+    print("teapot_resync.npz")
 
 
 def mk_teapot():
@@ -117,6 +146,7 @@ def mk_teapot():
 if __name__ == "__main__":
     mk_teapot()
     teapot()
+    teapot_resync()
     steps("area_sep", useAreaLight=1, useEnvMap=0, wfSeparateQueues=1)
     steps("env_area_single_rr", useAreaLight=1, useEnvMap=1, wfSeparateQueues=0, useRoulette=1)
     steps("denoiser_env_area_sep", denoiser=True, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)

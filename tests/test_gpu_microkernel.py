@@ -95,7 +95,9 @@ def test_microkernel_vs_reference_fixture():
     driver.render_single(g, p, int(z["spp"]))
     pg, ref = g.read_pixels(0), z["pixels"]
     assert np.array_equal(pg[:, 3], ref[:, 3])
-    close = np.isclose(pg[:, :3], ref[:, :3], rtol=2e-3, atol=2e-3).all(1)
-    assert close.mean() > 0.99, close.mean()            # a path flips only when an ulp-level difference moves a grazing ray
-    assert abs(pg[:, :3].mean() - ref[:, :3].mean()) <= 2e-3 * ref[:, :3].mean()
+    # a path flips only when an ulp-level difference (libm vs flx_math) moves a grazing ray, and then only its own pixel changes.
+    # Measured (the device is bit-identical to the oracle on this path): ALL 16 384 pixels within 1e-3, one pixel beyond 1e-4.
+    assert np.isclose(pg[:, :3], ref[:, :3], rtol=1e-3, atol=1e-3).all()
+    assert (~np.isclose(pg[:, :3], ref[:, :3], rtol=1e-4, atol=1e-4).all(1)).sum() <= 2
+    assert abs(pg[:, :3].mean() - ref[:, :3].mean()) <= 1e-5 * ref[:, :3].mean()
     assert np.array_equal(g.mk_stats()[[0, 3]], z["stats"][[0, 3]])

@@ -156,15 +156,32 @@ def test_golden_fixture_teapot():
         c = driver.benchmark_iteration(g, w * h)
         # hit/miss decisions of the reference kernels (libm) and ours (flx_math) agree on all but grazing rays
         assert np.all(np.abs(c.astype(np.int64) - cnts[it].astype(np.int64)) <= max(4, int(2e-3 * w * h))), (it, c, cnts[it])
+    # a FREE run against the reference's libm build forks at the first flipped grazing ray (see tests/test_oracle_golden.py); the exact
+    # device-vs-reference comparison is test_device_resynchronised_iterations_vs_reference_fixture below -- here the conserved quantities
     pg = g.read_pixels(0)
     ref = z["pixels"]
     assert np.abs(pg[:, 3] - ref[:, 3]).max() <= 3
-    m = (ref[:, 3] >= 1) & (pg[:, 3] == ref[:, 3])
-    img_g, img_r = pg[m, :3] / pg[m, 3:], ref[m, :3] / ref[m, 3:]
-    # free-running vs the reference's libm build: statistical agreement (see tests/test_oracle_golden.py for why)
-    close = np.isclose(img_g, img_r, rtol=1e-3, atol=1e-4).all(1)
-    assert close.mean() > 0.9
-    assert abs(img_g.mean() - img_r.mean()) <= 5e-3 * img_r.mean()
+    assert abs(pg[:, 3].sum() - ref[:, 3].sum()) <= 2e-3 * ref[:, 3].sum()
+    assert abs(pg[:, :3].sum() / pg[:, 3].sum() - ref[:, :3].sum() / ref[:, 3].sum()) <= 5e-3 * ref[:, :3].sum() / ref[:, 3].sum()
+
+
+def test_device_resynchronised_iterations_vs_reference_fixture():
+    """tests/golden/teapot_resync.npz (BASELINE.json configs[0] geometry, reference kernels): every iteration restarted from the
+    REFERENCE's state, so the device is compared with the reference exactly, iteration by iteration: counters ==, integers ==,
+    floats within the libm-vs-flx_math tolerance, framebuffer deltas, hit-index flips counted (<= 1 of 49 152 rays)."""
+    import os
+    import test_oracle_golden as og
+    from fluctus_amd.device import HipContext
+    path = os.path.join(common.GOLDEN, "teapot_resync.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden fixture missing")
+    z = np.load(path)
+    g = HipContext(int(z["num_tasks"]))
+    g.set_option("extend_tree", TRACE_MODE["ext"]); g.set_option("shadow_tree", TRACE_MODE["shadow"])
+    g.set_option("overlap", TRACE_MODE["overlap"])
+    g.upload_scene(og._load_scene(z)); g.set_params(z["params"].view(wire.RENDER_PARAMS).reshape(()))
+    rays, flips = og.resync_check(g, z, flip_budget=1)
+    assert rays == 12 * 4096
 
 
 def test_large_queue_properties():
@@ -343,10 +360,12 @@ def test_device_vs_reference_kernel_outputs(tag):
     if den:
         g.wf_reset()                               # feature buffers to their reset values
     names = [str(s) for s in z["names"]]
-    fn = {"logic": lambda: g.wf_logic(False), "materials": g.wf_materials, "extend": g.wf_extend, "shadow": g.wf_shadow}
+    fn = {"logic": lambda: g.wf_logic(False), "raygen": g.wf_raygen, "materials": g.wf_materials, "extend": g.wf_extend, "shadow": g.wf_shadow}
+    npix = int(p["width"]) * int(p["height"])
     for k in range(1, len(names)):
         if names[k] not in fn:
             continue
+        g.pixel_index_reset(); g.pixel_index_update(npix, int(z["pixel_cursor"][k - 1]))       # the reference's pixel cursor at that point
         g.state_import(z["states"][k - 1])
         for q in range(8):
             g.queue_write(q, z["queues"][k - 1][q])

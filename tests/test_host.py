@@ -60,6 +60,22 @@ def test_bvh_builders_produce_valid_trees(mode):
     assert abs(d.world_radius - 0.5 * np.linalg.norm(ext)) < 1e-5      # reference: src/tracer.cpp:66-67
 
 
+@pytest.mark.parametrize("gen,tris,seed", [("kitchen", 12000, 42), ("conference", 8000, 43), ("courtyard", 16000, 44)])
+def test_sbvh_parallel_build_is_the_serial_tree(gen, tris, seed):
+    """The parallel SBVH build (top of the tree: one node at a time with parallel sort + binning; below: independent subtrees as
+    parallel jobs) must return the serial recursion's node and index arrays byte for byte, for any thread count and job size --
+    the reference's builder (src/sbvh.cpp:105-157) is serial, and the tree decides traversal order and exact-tie winners."""
+    d = host.generate_scene(gen, tris, seed)
+    host.build_bvh(d, "sbvh", threads=1)
+    nodes, indices, met = d.nodes.copy(), d.indices.copy(), dict(d.bvh_metrics)
+    assert met["spatial_splits"] > 0
+    for threads, job in ((0, 0), (3, 500), (8, 64)):
+        host.build_bvh(d, "sbvh", threads=threads, job_size=job)
+        assert np.array_equal(d.nodes.view(np.uint8), nodes.view(np.uint8)), (threads, job)
+        assert np.array_equal(d.indices, indices), (threads, job)
+        assert d.bvh_metrics == met, (threads, job)
+
+
 def test_sbvh_creates_duplicates_only_with_spatial_splits():
     d = host.generate_scene("conference", 20000, 43)
     host.build_bvh(d, "sbvh")

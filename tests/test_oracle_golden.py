@@ -73,8 +73,7 @@ def test_kernel_steps_golden(tag):
         for q in range(8):
             c.queue_write(q, z["queues"][prev][q])
         c.set_counters(z["counters"][prev])
-        if names[k] == "raygen":
-            continue            # needs the reference's pixel cursor; covered by test_raygen_golden and the e2e fixture
+        c.pixel_index_reset(); c.pixel_index_update(npix, int(z["pixel_cursor"][prev]))     # the reference's cursor at that point
         if den:
             before = np.stack([c.read_pixels(4), c.read_pixels(5)])
         fn[names[k]]()
@@ -110,16 +109,56 @@ def test_teapot_end_to_end_golden():
         # free-running: ulp-level differences (libm vs flx_math) flip a few grazing rays per iteration (<= 1e-5 of rays
         # per kernel; they accumulate over iterations)
         assert np.all(np.abs(cnt.astype(np.int64) - cnts[it].astype(np.int64)) <= max(4, int(2e-3 * n))), (it, cnt, cnts[it])
+    # One flipped grazing ray changes when its path terminates, hence the order of the raygen queue and the pixel/seed pairing of
+    # every later regenerated path (src/wf_raygen.cl:25): a FREE run against the libm build forks.  The exact comparison is
+    # test_teapot_resynchronised_iterations_golden (every iteration restarted from the reference's state); here only the conserved
+    # quantities of the free run are checked.
     px, ref = c.read_pixels(0), z["pixels"]
     assert np.abs(px[:, 3] - ref[:, 3]).max() <= 3
-    m = (ref[:, 3] >= 1) & (px[:, 3] == ref[:, 3])
-    a, b = px[m, :3] / px[m, 3:], ref[m, :3] / ref[m, 3:]
-    close = np.isclose(a, b, rtol=1e-3, atol=1e-4).all(1)
-    # One flipped grazing ray changes when its path terminates, hence the order of the raygen queue and the pixel/seed pairing
-    # of every later regenerated path (src/wf_raygen.cl:25): after 24 free-running iterations ~5 % of the pixels hold different
-    # sample sets.  Per-kernel parity is pinned by test_kernel_steps_golden; here the check is statistical.
-    assert close.mean() > 0.9
-    assert abs(a.mean() - b.mean()) <= 5e-3 * b.mean()
+    assert abs(px[:, 3].sum() - ref[:, 3].sum()) <= 2e-3 * ref[:, 3].sum()
+    assert abs(px[:, :3].sum() / px[:, 3].sum() - ref[:, :3].sum() / ref[:, 3].sum()) <= 5e-3 * ref[:, :3].sum() / ref[:, 3].sum()
+
+
+def resync_check(c, z, flip_budget):
+    """Shared by the oracle (here) and the device (tests/test_gpu_parity.py): every iteration of tests/golden/teapot_resync.npz from
+    the REFERENCE's own pre-iteration state.  Returns (rays, flips).  Per iteration: queue counters exact; path state vs the
+    reference's next pre-state -- integers exact, floats rtol 1e-3 / atol 1e-4, except on paths whose hit
+    index flipped (counted, asserted against the budget); framebuffer delta of the iteration: sample counts exact where no flip
+    landed, sums rtol 1e-4."""
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    npix = int(p["width"]) * int(p["height"])
+    n = int(z["num_tasks"])
+    rays = flips = 0
+    for k in range(z["counters"].shape[0]):
+        c.state_import(z["states"][k])
+        c.set_counters(np.zeros(8, np.uint32))
+        c.pixel_index_reset(); c.pixel_index_update(npix, int(z["pixel_cursor"][k]))
+        before = c.read_pixels(0)
+        cnt = driver.benchmark_iteration(c, npix)
+        assert np.array_equal(cnt, z["counters"][k]), (k, cnt, z["counters"][k])
+        sa, sb = c.state_export(), z["states"][k + 1]
+        flip = sa.view(np.uint32)[COL.HIT_I] != sb.view(np.uint32)[COL.HIT_I]
+        rays += n; flips += int(flip.sum())
+        # one whole iteration chains the BSDF sample (sin / cos / atan2: libm vs flx_math, ~1e-7) into the next ray and its hit: on the
+        # teapot's high-curvature patches that moves an interpolated unit normal by up to ~3e-5 -> absolute tolerance 1e-4 here
+        # (per-kernel, from identical inputs: 1e-5, test_kernel_steps_golden)
+        fails = common.state_diff(sa, sb, 1e-3, 1e-4, mask=~flip)
+        assert not fails, f"iteration {k}: " + "; ".join(fails[:4])
+        got, want = c.read_pixels(0) - before, z["pixels"][k + 1] - z["pixels"][k]
+        assert np.array_equal(got[:, 3], want[:, 3]), f"iteration {k}: splat counts"
+        assert np.allclose(got, want, rtol=1e-4, atol=1e-5), f"iteration {k}: splat sums"
+    assert flips <= flip_budget, (rays, flips)
+    return rays, flips
+
+
+def test_teapot_resynchronised_iterations_golden():
+    """BASELINE.json configs[0] geometry on the wavefront path: 12 iterations, each restarted from the reference kernels' state
+    (tests/golden/teapot_resync.npz) -- the exact replacement for a statistical comparison of free-running images."""
+    z = _fixture("teapot_resync.npz")
+    c = OracleContext(int(z["num_tasks"]), threads=4)
+    c.upload_scene(_load_scene(z)); c.set_params(z["params"].view(wire.RENDER_PARAMS).reshape(()))
+    rays, flips = resync_check(c, z, flip_budget=1)
+    assert rays == 12 * 4096
 
 
 def test_thread_count_does_not_change_results():
@@ -149,7 +188,9 @@ def test_microkernel_teapot_16spp_golden():
     driver.render_single(c, p, int(z["spp"]))
     px, ref = c.read_pixels(0), z["pixels"]
     assert np.array_equal(px[:, 3], ref[:, 3]) and (px[:, 3] == 16).all()
-    close = np.isclose(px[:, :3], ref[:, :3], rtol=2e-3, atol=2e-3).all(1)
-    assert close.mean() > 0.99
-    assert abs(px[:, :3].mean() - ref[:, :3].mean()) <= 2e-3 * ref[:, :3].mean()
+    # one path per pixel, no cursor: a flipped ray can only touch its own pixel.  Measured: every one of the 16 384 pixels within 1e-3,
+    # ONE pixel beyond 1e-4 (libm vs flx_math in a 16-sample sum) -- asserted as such
+    assert np.isclose(px[:, :3], ref[:, :3], rtol=1e-3, atol=1e-3).all()
+    assert (~np.isclose(px[:, :3], ref[:, :3], rtol=1e-4, atol=1e-4).all(1)).sum() <= 2
+    assert abs(px[:, :3].mean() - ref[:, :3].mean()) <= 1e-5 * ref[:, :3].mean()
     assert np.array_equal(c.mk_stats()[[0, 3]], z["stats"][[0, 3]])
