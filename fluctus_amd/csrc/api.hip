@@ -24,7 +24,7 @@ void launch_materials(hipStream_t, const State &, const Queues &, const Scene &,
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
-void launch_state_export(hipStream_t, const State &, float *);
+void launch_state_export(hipStream_t, const State &, float *, float);
 void launch_state_import(hipStream_t, const State &, const float *);
 void launch_mk_reset(hipStream_t, const State &, const Frame &, const flx_render_params &);
 void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
@@ -896,7 +896,7 @@ int flx_state_export(flx_ctx *c, float *out)
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
     HIPCHK(c, hipMalloc((void **)&d, bytes));
-    launch_state_export(c->stream, c->st, d);
+    launch_state_export(c->stream, c->st, d, c->haveParams ? 2.0f * c->params.worldRadius : 0.0f);
     hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);

@@ -147,6 +147,18 @@ __device__ __forceinline__ void wr4(float4 *p, float4 v)
 #endif
 }
 
+// REGENERATED PATHS WITHOUT DEAD STORES.  genRays re-initialises the whole path state (src/wf_raygen.cl:77-96): 13 records per
+// regenerated path here, 9 of them values that nothing reads before a later kernel overwrites them (the hit record until
+// traceExtension; lastBsdf / lastSpecular until the material kernel; lastEmission / lastPdfDirect / shadowRayLen until logic's NEE),
+// three of those as 16-byte read-modify-writes for one member.  k_raygen writes only the four records that are live (orig, dir,
+// Ei + pixel, T + seed) and the three scalars, and marks the path with two flag bits carried in words it writes anyway:
+//   FLX_FRESH in pathLen   (DIR.w)  "no material kernel since regeneration": cleared by the material kernels when they write DIR
+//   FLX_FRESH in pixelIndex (EI.w)  "no NEE sample since regeneration":     cleared by logic when it writes a light sample
+// and pathLen == 0 means "not extended since regeneration".  flx_state_export substitutes the reference's reset values for the
+// members those flags cover, so exported states equal the reference's bit for bit after every kernel (the lockstep tests);
+// no kernel ever reads a covered member while its flag is set (each is read only behind shadowRayBlocked == 0 / pathLen > 1).
+#define FLX_FRESH 0x80000000u
+
 // wave64 helpers
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)

@@ -107,7 +107,9 @@ __device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, con
     wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(pathLenBits) + 1u));          // pathLen += 1
     wr4(st.at(S_HITP, gid), mk4(P, t));
     // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
-    const uint32_t keep = __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u;
+    // (genRays clears it; a regenerated path -- pathLen still 0 -- must not inherit the bit of the slot's previous path: flx_device.h)
+    const bool first = (__float_as_uint(pathLenBits) & ~FLX_FRESH) == 0u && (__float_as_uint(pathLenBits) & FLX_FRESH) != 0u;
+    const uint32_t keep = first ? 0u : (__float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u);
     wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
     wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
 }

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         const float4 huv = rd4(st.at(S_HITUV, gid));
         const float4 ei4 = rd4(st.at(S_EI, gid));
         uint32_t seed = __float_as_uint(thr.w);
-        const uint32_t len = __float_as_uint(d4.w);
+        const uint32_t len = __float_as_uint(d4.w) & ~FLX_FRESH;           // flag bits of a regenerated path: flx_device.h
+        const uint32_t pixIdx = __float_as_uint(ei4.w) & ~FLX_FRESH;
+        float eiw = ei4.w;                                                  // pixel index + "no NEE sample since regeneration"
         const f3 rayOrig = ld3(o4), rayDir = ld3(d4);
         const float lastPdfW = o4.w;
         f3 T = ld3(thr);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
 
         if (terminate) {                                              // splat + regenerate, :163-177
             if (len > 0u) {
-                float *px = fr.pixels + (size_t)__float_as_uint(ei4.w) * 4;
+                float *px = fr.pixels + (size_t)pixIdx * 4;
                 unsafeAtomicAdd(px + 0, Ei.x); unsafeAtomicAdd(px + 1, Ei.y);
                 unsafeAtomicAdd(px + 2, Ei.z); unsafeAtomicAdd(px + 3, 1.0f);
             }
@@ -137,7 +139,6 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             const f3 hitP = ld3(rd4(st.at(S_HITP, gid)));
             const f3 orig = hitP - 1e-3f * rayDir;
             if (fr.aovNormal) {                                       // denoiser features, :186-209
-                const uint32_t pixIdx = __float_as_uint(ei4.w);
                 if (len == 1u) {
                     const f3 n = camera_space_normal(p, hitN);
                     float *px = fr.aovNormal + (size_t)pixIdx * 4;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     wr4(st.at(S_SHD, gid), mk4(L, directPdfW));
                     wr4(st.at(S_LEMIT, gid), mk4(envMapLi, cosTh));
                     st.pickProb[gid] = envMapProb;
+                    eiw = __uint_as_float(pixIdx);
                     member |= 2u;
                 }
                 if (useAreaLight) {
@@ -189,13 +191,14 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                         wr4(st.at(S_SHD, gid), mk4(L, directPdfW));
                         wr4(st.at(S_LEMIT, gid), mk4(V(p.areaLight.E), cosTh));
                         st.pickProb[gid] = lightPickProb;
+                        eiw = __uint_as_float(pixIdx);
                         member |= 2u;
                     } else {
                         st.blocked[gid] = 1u;
                     }
                 }
             }
-            wr4(st.at(S_EI, gid), mk4(Ei, ei4.w));
+            wr4(st.at(S_EI, gid), mk4(Ei, eiw));
             wr4(st.at(S_THR, gid), mk4u(T, seed));
             (void)Tdirty;
             member |= material_list(mat.type, p.wfSeparateQueues) << 2;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
         wr4(st.at(S_LT, gid), mk4u(oldT, FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u));
         wr4(st.at(S_THR, gid), mk4u(newT, seed));
         wr4(st.at(S_ORIG, gid), mk4(orig, pdfW));
-        wr4(st.at(S_DIR, gid), mk4(newDir, d4.w));
+        wr4(st.at(S_DIR, gid), mk4u(newDir, __float_as_uint(d4.w) & ~FLX_FRESH));   // pathLen; "no material kernel since regeneration" ends here
     }
     if (active) {
         // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)

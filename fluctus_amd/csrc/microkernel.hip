@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_mk_reset(State st, Frame fr, flx_render
         reinterpret_cast<float4 *>(fr.aovAlbedo)[gid] = make_float4(0.1f, 0.1f, 0.1f, 0.0f);
     }
     st.phase[gid] = MK_GENERATE_CAMERA_RAY;
-    float4 ei = rd4(st.at(S_EI, gid)); wr4(st.at(S_EI, gid), make_float4(0.0f, 0.0f, 0.0f, ei.w));
+    float4 ei = rd4(st.at(S_EI, gid)); wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), __float_as_uint(ei.w) & ~FLX_FRESH));   // (drops a wavefront-path flag, flx_device.h)
     wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), gid));                                           // T = 1, seed = gid
     float4 d = rd4(st.at(S_DIR, gid)); d.w = __uint_as_float(0u); wr4(st.at(S_DIR, gid), d);      // pathLen
     float4 lt = rd4(st.at(S_LT, gid)); lt.w = __uint_as_float(1u); wr4(st.at(S_LT, gid), lt);     // lastSpecular

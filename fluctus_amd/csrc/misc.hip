@@ -85,10 +85,12 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         rayDirection = normalize(fp - rayOrig);
 
         wr4(st.at(S_ORIG, gid), mk4(rayOrig, 1.0f));                  // lastPdfW = 1
-        wr4(st.at(S_DIR, gid), mk4u(rayDirection, 0u));               // pathLen = 0
-        wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), localIdx));
+        wr4(st.at(S_DIR, gid), mk4u(rayDirection, FLX_FRESH | 0u));   // pathLen = 0; the rest of init_path_state's resets are
+        wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), FLX_FRESH | localIdx)); // implied by the two flags (flx_device.h), not stored
         wr4(st.at(S_THR, gid), mk4u(mk3(1.0f), seed));
-        init_path_state(st, gid, 2.0f * p.worldRadius);
+        st.pickProb[gid] = 1.0f;                                       // read by the MIS weights before any NEE may have written it
+        st.blocked[gid] = 1u;
+        st.firstDiffuse[gid] = 0u;
     }
     if (active) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;   // extBase + index (see flx_device.h)
 }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_postprocess(Frame fr, flx_render
 }
 
 // ---- test hooks: internal packed layout <-> reference 64-column SoA (src/geom.h:199-236)
-__global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *out)
+__global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *out, float shadowLenReset)
 {
     const uint32_t gid = blockIdx.x * MISC_BLOCK + threadIdx.x;
     const uint32_t N = st.numTasks;
@@ -154,20 +156,33 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_export(State st, float *ou
     auto W = [&](int col, float v) { out[(size_t)col * N + gid] = v; };
     auto W3 = [&](int col, float4 v) { W(col, v.x); W(col + 1, v.y); W(col + 2, v.z); W(col + 3, 0.0f); };
     float4 r;
+    // the flags of a regenerated path (flx_device.h): members they cover are exported with genRays' reset values (src/wf_raygen.cl:77-96)
     r = rd4(st.at(S_ORIG, gid)); W3(FLX_COL_ORIG, r); W(FLX_COL_LAST_PDF_W, r.w);
-    r = rd4(st.at(S_DIR, gid)); W3(FLX_COL_DIR, r); W(FLX_COL_PATH_LEN, r.w);
-    r = rd4(st.at(S_SHO, gid)); W3(FLX_COL_SHADOW_ORIG, r); W(FLX_COL_SHADOW_LEN, r.w);
-    r = rd4(st.at(S_SHD, gid)); W3(FLX_COL_SHADOW_DIR, r); W(FLX_COL_LAST_PDF_DIRECT, r.w);
+    r = rd4(st.at(S_DIR, gid)); W3(FLX_COL_DIR, r);
+    const uint32_t lenBits = __float_as_uint(r.w);
+    const bool noMaterial = (lenBits & FLX_FRESH) != 0u, notExtended = noMaterial && (lenBits & ~FLX_FRESH) == 0u;
+    W(FLX_COL_PATH_LEN, __uint_as_float(lenBits & ~FLX_FRESH));
+    r = rd4(st.at(S_EI, gid)); W3(FLX_COL_EI, r);
+    const bool noNee = (__float_as_uint(r.w) & FLX_FRESH) != 0u;
+    W(FLX_COL_PIXEL_INDEX, __uint_as_float(__float_as_uint(r.w) & ~FLX_FRESH));
+    r = rd4(st.at(S_SHO, gid)); W3(FLX_COL_SHADOW_ORIG, r); W(FLX_COL_SHADOW_LEN, noNee ? shadowLenReset : r.w);
+    r = rd4(st.at(S_SHD, gid)); W3(FLX_COL_SHADOW_DIR, r); W(FLX_COL_LAST_PDF_DIRECT, noNee ? 0.0f : r.w);
     r = rd4(st.at(S_THR, gid)); W3(FLX_COL_T, r); W(FLX_COL_SEED, r.w);
-    r = rd4(st.at(S_EI, gid)); W3(FLX_COL_EI, r); W(FLX_COL_PIXEL_INDEX, r.w);
-    r = rd4(st.at(S_LBSDF, gid)); W3(FLX_COL_LAST_BSDF, r); W(FLX_COL_LAST_PDF_IMPLICIT, r.w);
-    r = rd4(st.at(S_LEMIT, gid)); W3(FLX_COL_LAST_EMISSION, r); W(FLX_COL_LAST_COS_TH, r.w);
-    r = rd4(st.at(S_LT, gid)); W3(FLX_COL_LAST_T, r); W(FLX_COL_LAST_SPECULAR, r.w);
-    r = rd4(st.at(S_HITP, gid)); W3(FLX_COL_P, r); W(FLX_COL_HIT_T, r.w);
-    r = rd4(st.at(S_HITN, gid)); W3(FLX_COL_N, r);
+    r = rd4(st.at(S_LBSDF, gid)); if (noMaterial) r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    W3(FLX_COL_LAST_BSDF, r); W(FLX_COL_LAST_PDF_IMPLICIT, r.w);
+    r = rd4(st.at(S_LEMIT, gid)); if (noNee) r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    W3(FLX_COL_LAST_EMISSION, r); W(FLX_COL_LAST_COS_TH, r.w);
+    r = rd4(st.at(S_LT, gid)); W3(FLX_COL_LAST_T, r); W(FLX_COL_LAST_SPECULAR, noMaterial ? __uint_as_float(1u) : r.w);
+    r = rd4(st.at(S_HITP, gid)); if (notExtended) r = make_float4(0.0f, 0.0f, 0.0f, FLX_FLT_MAX);
+    W3(FLX_COL_P, r); W(FLX_COL_HIT_T, r.w);
+    r = rd4(st.at(S_HITN, gid)); if (notExtended) r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    W3(FLX_COL_N, r);
+    // backfaceHit: logic's, reset by genRays; a regenerated path keeps it clear until logic shades its first hit (commit_hit drops the
+    // stale bit of the slot's previous path when it extends a fresh ray)
     const uint32_t fl = __float_as_uint(r.w);
     W(FLX_COL_AREA_LIGHT_HIT, __uint_as_float(fl & 1u)); W(FLX_COL_BACKFACE, __uint_as_float((fl >> 1) & 1u));
-    r = rd4(st.at(S_HITUV, gid)); W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
+    r = rd4(st.at(S_HITUV, gid)); if (notExtended) r = make_float4(0.0f, 0.0f, __int_as_float(-1), __int_as_float(-1));
+    W(FLX_COL_UV, r.x); W(FLX_COL_UV + 1, r.y); W(FLX_COL_HIT_I, r.z); W(FLX_COL_MAT_ID, r.w);
     W(FLX_COL_PHASE, __uint_as_float(st.phase[gid]));
     W(FLX_COL_SHADOW_BLOCKED, __uint_as_float(st.blocked[gid]));
     W(FLX_COL_LAST_PICK_PROB, st.pickProb[gid]);
@@ -229,9 +244,9 @@ void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params 
 {
     hipLaunchKernelGGL(k_postprocess, dim3((fr.localPixels + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, fr, p);
 }
-void launch_state_export(hipStream_t s, const State &st, float *out)
+void launch_state_export(hipStream_t s, const State &st, float *out, float shadowLenReset)
 {
-    hipLaunchKernelGGL(k_state_export, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, out);
+    hipLaunchKernelGGL(k_state_export, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, out, shadowLenReset);
 }
 void launch_state_import(hipStream_t s, const State &st, const float *in)
 {

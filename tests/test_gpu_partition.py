@@ -94,6 +94,7 @@ def test_partition_free_run_and_device_copy(rank, world):
     assert np.array_equal(pg[:, 3], po[:, 3]) and np.allclose(pg, po, rtol=1e-6, atol=1e-7)
     maxlp = (w * h + world - 1) // world
     tile = torch.full((maxlp, 4), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()                   # the fill runs on torch's stream, the copy on the context's: order them
     g.copy_pixels_to_device(tile.data_ptr())
     g.finish()
     torch.cuda.synchronize()
