@@ -293,6 +293,18 @@ def main():
         step_async(ctx)
     ctx.finish()
     st = ctx.stats()
+    own_leaf = ctx.leaf_stats() if (C == 1 and args.extend_tree == 4) else None
+    st_own = dict(st)
+    if args.extend_tree == 4 or args.shadow_tree == 4:
+        # SURVEY 8(d) defines the algorithmic bytes through the visit counts of the REFERENCE traversal (binary tree, near child first) on
+        # the same BVH: count them with the binary kernels on the same steady state (untimed); st_own keeps what the 4-wide kernels did
+        ctx.set_option("extend_tree", 2); ctx.set_option("shadow_tree", 2)
+        ctx.reset_stats()
+        for _ in range(4):
+            step_async(ctx)
+        ctx.finish()
+        st = ctx.stats()
+        ctx.set_option("extend_tree", args.extend_tree); ctx.set_option("shadow_tree", args.shadow_tree)
     simd = None
     if C == 1:
         ws = ctx.wave_stats()
@@ -305,6 +317,12 @@ def main():
     ctx.trace_stats_enable(False)
     ext_bytes, sh_bytes = algorithmic_bytes(st)
     bytes_per_ext_ray = ext_bytes / max(1, st["ext_rays"])
+    # what the kernel that ran really touches per ray: 84 B of path state + one 64-B record per wide-node visit + 32 B per leaf header
+    # + 48 B per triangle record + the 64-B shading record of a hit
+    own_bytes_per_ray = None
+    if own_leaf is not None:
+        own_bytes_per_ray = (84 * st_own["ext_rays"] + 64 * st_own["ext_inner"] + 32 * own_leaf["ext_leaf"] + 48 * st_own["ext_tri"]
+                             + 64 * st_own["ext_hits"]) / max(1, st_own["ext_rays"])
     ext_ms, ext_n = prof["extend"]
     rays_per_launch = ext / world / C / max(1, args.steps)
     achieved = (bytes_per_ext_ray * rays_per_launch) / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 if ext_ms > 0 else 0.0
@@ -320,7 +338,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))          # PMC capture of one configuration: only quoted for that configuration
-            if tj.get("num_tasks") == args.num_tasks // C and tj.get("workload") == args.workload:
+            if tj.get("num_tasks") == args.num_tasks // C and tj.get("workload") == args.workload and tj.get("extend_tree") == args.extend_tree:
                 traffic = tj.get("extend_hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -381,8 +399,18 @@ def main():
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},
             "kernel_ms_avg": {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items() if v[1]},
             "kernel_ms_avg_source": {"timed_region": sorted(k for k, v in prof.items() if v[1] and k not in untimed), "extra_untimed_pass": sorted(untimed)},
-            "roofline": {"kernel": "traceExtension (k_extend)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "traceExtension (k_extend4: 4-wide quantised tree)" if args.extend_tree == 4 else "traceExtension (k_extend: binary tree)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "definition": "achieved = SURVEY 8(d) algorithmic bytes of the REFERENCE traversal (84 + 64 n_inner + 40 n_tri + 64 [hit] per ray, binary tree, "
+                                       "near child first; counted on the same rays) x rays per launch / HIP-event launch time.  These bytes are served by L2 / Infinity "
+                                       "Cache for this scene: frac_traffic is the fabric-side counter traffic over the same time, frac_own the bytes the running kernel touches",
+                         "frac_traffic": (traffic / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ext_ms > 0) else None,
+                         "own_bytes_per_ray": own_bytes_per_ray,
+                         "frac_own": (own_bytes_per_ray * rays_per_launch / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (own_bytes_per_ray and ext_ms > 0) else None,
+                         "own_avg_wide_node_visits": (st_own["ext_inner"] / max(1, st_own["ext_rays"])) if own_leaf is not None else None,
+                         "own_avg_leaf_visits": (own_leaf["ext_leaf"] / max(1, st_own["ext_rays"])) if own_leaf is not None else None,
+                         "own_avg_tri_tests": (st_own["ext_tri"] / max(1, st_own["ext_rays"])) if own_leaf is not None else None,
                          "bytes_per_ray": bytes_per_ext_ray,
                          "avg_inner_visits": st["ext_inner"] / max(1, st["ext_rays"]),
                          "avg_tri_tests": st["ext_tri"] / max(1, st["ext_rays"]),
