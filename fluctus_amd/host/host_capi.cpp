@@ -183,7 +183,7 @@ int fh_tracer_load_state(void *t) { return ((Tracer *)t)->loadState() ? 0 : 1; }
 int fh_tracer_scene_hash(void *t, char *out, uint64_t cap) { const std::string &h = ((Tracer *)t)->getSceneHash(); if (h.size() + 1 > cap) return 1; memcpy(out, h.c_str(), h.size() + 1); return 0; }
 uint64_t fh_xxh64(const void *data, uint64_t len, uint64_t seed) { return xxh64(data, (size_t)len, seed); }
 int fh_tracer_render_single(void *t, int spp, int denoise) { FH_TRY ((Tracer *)t)->renderSingle(spp, denoise != 0); FH_CATCH }
-int fh_tracer_set_option(void *t, const char *name, int value) { FH_TRY ((Tracer *)t)->getContext()->setOption(name ? name : "", value); FH_CATCH }
+int fh_tracer_set_option(void *t, const char *name, int value) { FH_TRY ((Tracer *)t)->setOption(name ? name : "", value); FH_CATCH }
 int fh_tracer_set_denoiser(void *t, int on) { FH_TRY ((Tracer *)t)->setDenoiser(on != 0); FH_CATCH }
 int fh_tracer_toggle_renderer(void *t) { FH_TRY ((Tracer *)t)->toggleRenderer(); FH_CATCH }
 int fh_tracer_uses_wavefront(void *t) { return ((Tracer *)t)->usesWavefront() ? 1 : 0; }

@@ -36,6 +36,7 @@ public:
     void renderSingle(int spp, bool denoise = false);                             // denoise: also fill the denoiser feature buffers
     void setDenoiser(bool on) { useDenoiser = on; for (auto *c : ranks()) c->recompileKernels(on); iteration = 0; }
     void toggleRenderer() { useWavefront = !useWavefront; iteration = 0; }        // src/tracer.cpp:881-886
+    void setOption(const std::string &name, int value) { for (auto *c : ranks()) c->setOption(name, value); }   // every rank (HipContext::setOption)
     bool usesWavefront() const { return useWavefront; }
     void saveImage(const std::string &filename) { clctx->saveImage(filename, params); }
 

@@ -166,7 +166,7 @@ def test_cpp_tracer_drives_several_ranks_from_one_process():
     scene = "proc:conference:12000:43"
     t = Tracer(w, h, [0] * R, n)
     assert t.num_ranks == R
-    t.set_option("extend_tree", 2)           # rank 0 ...
+    t.set_option("extend_tree", 2)           # every rank: the reference's visit order, so that the comparison below is exact
     t.init(w, h, scene)
     p = t.params
     wire.look_at(p, (0.0, 1.2, 2.6), (0.0, 0.2, 0.0))
@@ -180,8 +180,6 @@ def test_cpp_tracer_drives_several_ranks_from_one_process():
         o = OracleContext(n, threads=8)
         o.upload_scene(d); o.set_partition(r, R); o.set_params(p)
         orc.append(o)
-    # the 4-wide closest-hit kernel is the default on ranks 1, 2 (set_option above reaches rank 0 only): flips are ~1e-7 per ray, so
-    # the run is compared through sums that a flipped ray would change
     tot = t.update()
     want = sum(driver.first_frame(o, p, multi.local_pixel_count(w * h, r, R)) for r, o in enumerate(orc))
     assert (tot == want).all(), (tot, want)
