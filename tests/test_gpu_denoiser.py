@@ -40,12 +40,15 @@ def test_wavefront_features_lockstep(sep, overlap):
         for which in (4, 5):
             a, b = g.read_pixels(which), o.read_pixels(which)
             assert np.array_equal(a[:, 3], b[:, 3])                                  # counts: exact
-            assert np.allclose(a, b, rtol=1e-6, atol=1e-7), (it, which)             # sums: atomic order within a pixel
+            # sums: the order of the float atomics within a pixel is free.  The normal buffer adds SIGNED components of unit vectors, so a
+            # sum can cancel to near zero while every partial sum is O(count): absolute tolerance per add, relative tolerance on top
+            tol = 1e-6 * np.abs(b) + 2e-7 * np.maximum(1.0, b[:, 3:4])
+            assert (np.abs(a - b) <= tol).all(), (it, which, float(np.abs(a - b).max()))
         cnt = driver_step_rest(g, o, w * h)
     for c in (g, o):
         c.postprocess()
     for which in (2, 3):
-        assert np.allclose(g.read_pixels(which), o.read_pixels(which), rtol=1e-6, atol=1e-7)
+        assert np.allclose(g.read_pixels(which), o.read_pixels(which), rtol=1e-6, atol=1e-6)       # resolved sums / count: see above
     assert g.read_pixels(5)[:, 3].sum() > 0
 
 
