@@ -170,7 +170,9 @@ std::vector<MtlEntry> readMtl(const std::string &path)
         if (k == "Kd") rd3(e.m.Kd); else if (k == "Ks") rd3(e.m.Ks); else if (k == "Ke") rd3(e.m.Ke);
         else if (k == "Ns") iss >> e.m.Ns; else if (k == "Ni") iss >> e.m.Ni;
         else if (k == "map_Kd") iss >> e.mapKd; else if (k == "map_Ks") iss >> e.mapKs;
-        else if (k == "map_bump" || k == "map_Bump" || k == "bump") iss >> e.mapBump;
+        // case-sensitive like the reference's vendored tinyobj (include/tiny_obj_loader.h:1220-1229): `map_Bump`, as Country-Kitchen.mtl
+        // spells it, is NOT a bump map there (it lands in unknown_parameter), so the reference renders the carrots without one
+        else if (k == "map_bump" || k == "bump") iss >> e.mapBump;
         else if (k == "shader") iss >> e.shader;
     }
     return out;
