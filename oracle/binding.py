@@ -54,6 +54,25 @@ def ref_lib():
     return _ref_lib
 
 
+_refbvh_lib = None
+
+
+def refbvh_lib():
+    """oracle/_ref/libfluctus_refbvh.so: the reference's own object-split BVH builder (src/bvh.cpp, src/bvhnode.cpp) compiled
+    unmodified (oracle/ref/Makefile, oracle/ref/bvh_driver.cpp); this container only."""
+    global _refbvh_lib
+    if _refbvh_lib is None:
+        path = os.path.join(_HERE, "_ref", "libfluctus_refbvh.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        _refbvh_lib = C.CDLL(path)
+    return _refbvh_lib
+
+
+def refbvh_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libfluctus_refbvh.so"))
+
+
 def ref_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libfluctus_ref.so"))
 

@@ -646,3 +646,34 @@ def test_mtl_parser_matches_the_reference_parser_on_the_material_libraries(tmp_p
             ntex += exists
     if folder == "country_kitchen":
         assert len(names) == 96 and ntex >= 17
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("scene", ["teapot", "small", "conference-38k", "kitchen-30k"])
+def test_sah_bvh_is_the_reference_builders_tree(tmp_path, scene):
+    """SURVEY A12 / G8, for the builder that CAN be built here: the reference's own `class BVH` (src/bvh.cpp + src/bvhnode.cpp compiled
+    unmodified into oracle/_ref/libfluctus_refbvh.so) builds the tree with SplitMode::SAH and writes it with its own BVH::exportTo;
+    host/bvh.cpp's Mode::SAH must produce the SAME node array and index list, byte for byte, and host/bvh.cpp's importFrom must read the
+    reference's file (the on-disk cache format of src/bvh.cpp:147-192, incl. its node-count quirk).  (src/sbvh.cpp, the builder
+    Tracer::initHierarchy uses, includes progressview.hpp -> glad / GLFW / nanogui and cannot be built; our SBVH shares the sort,
+    sweep and tie-break rules pinned here.)"""
+    import ctypes as C
+    from oracle.binding import refbvh_available, refbvh_lib
+    if not refbvh_available():
+        pytest.skip("oracle/_ref/libfluctus_refbvh.so not built (needs /root/reference)")
+    if scene == "teapot":
+        if not os.path.exists(REF + "/teapot.ply"):
+            pytest.skip("teapot.ply not in the checkout")
+        d = host.load_scene(REF + "/teapot.ply")
+    elif scene == "small":
+        d = common.small_mesh_scene(n=6)
+    elif scene == "conference-38k":
+        d = host.generate_scene("conference", 6000, 43)
+    else:
+        d = host.generate_scene("kitchen", 30000, 42)
+    f = str(tmp_path / "ref_hierarchy.bin")
+    assert refbvh_lib().ref_bvh_build_export(d.tris.ctypes.data_as(C.c_void_p), C.c_uint64(d.tris.size), 0, f.encode()) == 0
+    rn, ri = host.bvh_import(f)
+    host.build_bvh(d, "sah")
+    assert rn.size == d.nodes.size and np.array_equal(ri, d.indices)
+    assert np.array_equal(rn.view(np.uint8), d.nodes.view(np.uint8))
