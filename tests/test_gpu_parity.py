@@ -119,6 +119,28 @@ def test_free_running_render_bit_identical(sep):
     _free_run(g, o, w * h, 40)
 
 
+@pytest.mark.parametrize("area,env,expl,impl,sep,roulette", [
+    (1, 0, 1, 1, 1, 0), (0, 1, 1, 1, 1, 0), (1, 1, 1, 1, 0, 1), (1, 1, 1, 0, 1, 0), (1, 1, 0, 1, 1, 0), (0, 0, 1, 1, 1, 1)])
+def test_free_running_flag_matrix(area, env, expl, impl, sep, roulette):
+    """The six flag sets of the lockstep matrix, FREE-running for 30 iterations (no state import in between): this is where the
+    regenerated-path flag bits (flx_device.h: k_raygen stores only the live records) live through logic / materials / extend and
+    where the export fix-up has to reproduce genRays' reset values -- final state, counters and image against the oracle."""
+    d = common.mixed_material_scene()
+    w, h, n = 72, 50, 8192
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=area, useEnvMap=env, sampleExpl=expl, sampleImpl=impl,
+                            wfSeparateQueues=sep, useRoulette=roulette, envMapStrength=1.5)
+    g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
+    for it in range(30):
+        cg = driver.benchmark_iteration(g, w * h)
+        co = driver.benchmark_iteration(o, w * h)
+        assert (cg == co).all(), f"iteration {it}: counters {cg} vs {co}"
+        if it in (0, 1, 7, 29):                       # incl. the states right after the first regenerations
+            fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+            assert not fails, f"iteration {it}: " + "; ".join(fails[:5])
+    pg, po = g.read_pixels(0), o.read_pixels(0)
+    assert np.array_equal(pg[:, 3], po[:, 3]) and np.allclose(pg, po, rtol=1e-6, atol=1e-7)
+
+
 def test_first_frame_preview_path():
     d = common.simple_scene()
     w, h, n = 40, 30, 2048
