@@ -85,9 +85,9 @@ def _free_run(g, o, npix, iters):
     assert not fails, "; ".join(fails[:5])
     pg, po = g.read_pixels(0), o.read_pixels(0)
     assert np.array_equal(pg[:, 3], po[:, 3]), "sample counts differ"
-    assert np.allclose(pg, po, rtol=1e-6, atol=1e-7), "radiance sums differ"
+    assert common.fb_close(pg, po), "radiance sums differ"
     g.postprocess(); o.postprocess()
-    assert np.allclose(g.read_pixels(1), o.read_pixels(1), rtol=1e-6, atol=1e-7)
+    assert np.allclose(g.read_pixels(1), o.read_pixels(1), rtol=4e-6, atol=1e-6)      # resolved + tone-mapped: derived from the sums above
 
 
 def test_lockstep_simple_area_light():
@@ -138,7 +138,7 @@ def test_free_running_flag_matrix(area, env, expl, impl, sep, roulette):
             fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
             assert not fails, f"iteration {it}: " + "; ".join(fails[:5])
     pg, po = g.read_pixels(0), o.read_pixels(0)
-    assert np.array_equal(pg[:, 3], po[:, 3]) and np.allclose(pg, po, rtol=1e-6, atol=1e-7)
+    assert common.fb_close(pg, po)
 
 
 def test_first_frame_preview_path():
@@ -275,7 +275,7 @@ def test_full_size_properties_and_determinism(workload):
         g.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert not common.state_diff(outs[0][1], outs[1][1], 0.0, 0.0)
-    assert np.array_equal(outs[0][2][:, 3], outs[1][2][:, 3]) and np.allclose(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-7)
+    assert common.fb_close(outs[0][2], outs[1][2])
 
 
 def test_c_abi_error_paths():

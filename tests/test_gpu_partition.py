@@ -72,7 +72,7 @@ def test_partition_lockstep_vs_oracle(rank, world):
     pg, po = g.read_pixels(0), o.read_pixels(0)[:lp]
     assert pg.shape == (lp, 4)
     assert np.array_equal(pg[:, 3], po[:, 3]) and pg[:, 3].sum() > 0
-    assert np.allclose(pg, po, rtol=1e-6, atol=1e-7)
+    assert common.fb_close(pg, po)
 
 
 @pytest.mark.parametrize("rank,world", [(0, 1), (1, 3), (7, 8)])
@@ -91,7 +91,7 @@ def test_partition_free_run_and_device_copy(rank, world):
         assert (cg == co).all(), f"iteration {it}: counters {cg} vs {co}"
     assert not common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
     pg, po = g.read_pixels(0), o.read_pixels(0)[:lp]
-    assert np.array_equal(pg[:, 3], po[:, 3]) and np.allclose(pg, po, rtol=1e-6, atol=1e-7)
+    assert common.fb_close(pg, po)
     maxlp = (w * h + world - 1) // world
     tile = torch.full((maxlp, 4), -1.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()                   # the fill runs on torch's stream, the copy on the context's: order them
@@ -195,4 +195,4 @@ def test_native_gather_over_rccl_single_rank():
     assert np.array_equal(device.gather_local([g2], 0), g2.read_pixels(0))
     # same scene, same seeds: the same render (sums up to the order of the float atomics of paths sharing a pixel)
     again = device.gather_local([g2], 0)
-    assert np.array_equal(again[:, 3], full[:, 3]) and np.allclose(again, full, rtol=1e-6, atol=1e-7)
+    assert common.fb_close(again, full)
