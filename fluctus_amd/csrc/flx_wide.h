@@ -107,10 +107,55 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
         const double dx = (double)n.bmax.x - n.bmin.x, dy = (double)n.bmax.y - n.bmin.y, dz = (double)n.bmax.z - n.bmin.z;
         return dx * dy + dy * dz + dz * dx;
     };
+    std::vector<uint8_t> seen(nnodes, 0);
+    // ---- which binary inner nodes become wide nodes: the SAH-optimal choice (Ylitie, Karras, Laine 2017, section 3).  The leaves are
+    // fixed, so the expected traversal cost is  sum over the binary nodes that become wide nodes of their surface area.
+    // cost[n][i-1] = least such sum for the subtree of n represented as a FOREST of at most i roots (i = 1..3); a wide node rooted at n
+    // hands its 4 slots to the two subtrees in the cheapest way (k | 4 - k).  Nodes are in DFS order (children after parents).
+    std::vector<float> cost;      // 3 per node
+    std::vector<uint8_t> split4;  // per inner node: slots given to the LEFT subtree when n roots a wide node (1..3)
+    std::vector<uint8_t> splitF;  // per inner node: for the forest of <= 2 / <= 3 roots: low nibble i=2, high nibble i=3; 0 = "use fewer roots"
+    {
+        cost.assign(nnodes * 3, 0.0f); split4.assign(nnodes, 0); splitF.assign(nnodes, 0);
+        for (size_t ii = nnodes; ii-- > 0;) {
+            if (nodes[ii].nPrims) continue;                                   // leaf: 0 for every i
+            const uint32_t l = (uint32_t)ii + 1, r = nodes[ii].iStartOrRight;
+            if (l >= nnodes || r >= nnodes || r <= ii) return fail("wide tree: child index out of range");
+            auto C = [&](uint32_t n, int i) { return cost[(size_t)n * 3 + (i - 1)]; };     // i in 1..3
+            auto distribute = [&](int j, int *bestk) {                        // j roots over the two children, each >= 1
+                float best = 3.0e38f; int bk = 1;
+                for (int k = 1; k < j; k++) { const float c = C(l, k > 3 ? 3 : k) + C(r, (j - k) > 3 ? 3 : (j - k)); if (c < best) { best = c; bk = k; } }
+                *bestk = bk; return best;
+            };
+            int k4 = 1;
+            const float c1 = (float)area((uint32_t)ii) + distribute(4, &k4);
+            split4[ii] = (uint8_t)k4;
+            cost[ii * 3 + 0] = c1;
+            int k2 = 1, k3 = 1;
+            const float d2 = distribute(2, &k2), d3 = distribute(3, &k3);
+            float c2 = c1; uint8_t f = 0;
+            if (d2 < c2) { c2 = d2; f |= (uint8_t)k2; }
+            float c3 = c2; uint8_t f3 = 0;
+            if (d3 < c3) { c3 = d3; f3 = (uint8_t)k3; }
+            cost[ii * 3 + 1] = c2; cost[ii * 3 + 2] = c3;
+            splitF[ii] = (uint8_t)(f | (f3 << 4));
+        }
+    }
+    // the binary nodes that form the forest of at most `i` roots under n, left to right
+    auto forest = [&](uint32_t n, int i, uint32_t *outSlots, int &ns, auto &&self) -> bool {
+        if (nodes[n].nPrims || i == 1) { outSlots[ns++] = n; return true; }
+        const uint32_t l = n + 1, r = nodes[n].iStartOrRight;
+        int k = i == 3 ? (splitF[n] >> 4) : 0;
+        if (i == 3 && k == 0) return self(n, 2, outSlots, ns, self);         // three roots are no better than two
+        if (i == 2) { k = splitF[n] & 15; if (k == 0) { outSlots[ns++] = n; return true; } }
+        if (seen[n]) return false;
+        seen[n] = 1;                                                          // opened: it will not get a record of its own
+        return self(l, k, outSlots, ns, self) && self(r, i - k, outSlots, ns, self);
+    };
+
     // ---- collapse, wide nodes numbered so that the (up to 4) inner children of a node are consecutive records
     struct Item { uint32_t bin; uint32_t wide; uint32_t stackAbove; };      // binary inner node -> wide record; stack entries pending above it
     std::vector<Item> todo;
-    std::vector<uint8_t> seen(nnodes, 0);
     out.nodes.resize(1);
     todo.push_back({0u, 0u, 0u});
     seen[0] = 1;
@@ -123,17 +168,11 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
             if (l >= nnodes || r >= nnodes || r <= it.bin) return fail("wide tree: child index out of range");
             slots[ns++] = l; slots[ns++] = r;
         }
-        while (ns < 4) {                 // open the inner child with the largest surface area (children keep their left-to-right order)
-            int best = -1; double ba = -1.0;
-            for (int k = 0; k < ns; k++) if (!nodes[slots[k]].nPrims) { const double a = area(slots[k]); if (a > ba) { ba = a; best = k; } }
-            if (best < 0) break;
-            const uint32_t b = slots[best];
-            const uint32_t l = b + 1, r = nodes[b].iStartOrRight;
-            if (l >= nnodes || r >= nnodes || r <= b) return fail("wide tree: child index out of range");
-            if (seen[b]) return fail("wide tree: node reachable twice (cyclic or shared node array)");
-            seen[b] = 1;
-            for (int k = ns; k > best + 1; k--) slots[k] = slots[k - 1];
-            slots[best] = l; slots[best + 1] = r; ns++;
+        {
+            const uint32_t l = slots[0], r = slots[1];
+            const int k = split4[it.bin];
+            ns = 0;
+            if (!forest(l, k, slots, ns, forest) || !forest(r, 4 - k, slots, ns, forest)) return fail("wide tree: node reachable twice (cyclic or shared node array)");
         }
         // nesting: every slot's box inside this node's box (transitively, through the opened intermediate nodes)
         const flx_node &P = nodes[it.bin];
