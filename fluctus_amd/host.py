@@ -130,6 +130,17 @@ def build_bvh(d, mode="sbvh", threads=0, job_size=0):
     return d
 
 
+def wide_tree_check(d):
+    """Build the traversal kernels' 4-wide quantised tree (csrc/flx_wide.h -- what flx_upload_scene builds) on the CPU and check its
+    invariants: conservative quantised boxes, every binary leaf exactly once with its box / count / triangle order, every wide node
+    reachable once, unused slots inverted.  Raises on a violation; returns the tree's figures."""
+    out = (C.c_uint64 * 8)()
+    _chk(lib().fh_wide_tree_check(_p(d.nodes), C.c_uint64(d.nodes.size), _p(d.tris), C.c_uint64(d.tris.size),
+                                  _p(d.indices), C.c_uint64(d.indices.size), out))
+    return dict(wide_nodes=out[0], leaf_float4s=out[1], max_stack=out[2], nested=bool(out[3]), leaves=out[4],
+                slots_used={2: out[5], 3: out[6], 4: out[7]})
+
+
 def bvh_export(d, path, mode="sbvh"):
     """Build and write the hierarchy cache file (the reference's on-disk format, host/bvh.hpp)."""
     L = lib()

@@ -6,6 +6,7 @@
 #include "bvh.hpp"
 #include "envmap.hpp"
 #include "texture.hpp"
+#include "../csrc/flx_wide.h"      // the 4-wide tree builder is plain host C++ (flx_upload_scene runs it); exposed here for CPU-side tests
 #include <cstring>
 #include <string>
 #include <exception>
@@ -100,6 +101,93 @@ int fh_bvh_build_ex(const void *tris, uint64_t ntris, int mode, int threads, uin
     catch (...) { delete copy; delete b; throw; }
     delete copy;
     *out = b;
+    FH_CATCH
+}
+// Build the 4-wide quantised tree of a scene on the CPU exactly as flx_upload_scene does and CHECK its invariants (tests/test_host.py):
+//  every quantised child box contains the child's exact box (real arithmetic), every binary leaf is referenced exactly once and its
+//  block carries the leaf's box, count and triangles, every inner record is referenced exactly once, unused slots point at the dummy
+//  leaf.  out8 = {wide nodes, leaf data float4s, stack bound, nested, leaves, max children per node histogram packed: [5]=2-slot nodes,
+//  [6]=3-slot, [7]=4-slot}.
+int fh_wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, uint64_t ntris, const uint32_t *indices, uint64_t nidx, uint64_t *out8)
+{
+    FH_TRY
+    const flx_node *nodes = (const flx_node *)nodesv;
+    const flx_triangle *tris = (const flx_triangle *)trisv;
+    flxw::WideTree w; const char *err = nullptr;
+    if (!flxw::build_wide(nodes, nnodes, tris, ntris, indices, nidx, w, &err)) throw std::runtime_error(err ? err : "build_wide failed");
+    // leaf blocks by offset
+    std::vector<uint32_t> leafOfOffset(w.leafdata.size(), 0xFFFFFFFFu);
+    uint64_t nleaves = 0;
+    {
+        size_t off = 5;                                                   // after the dummy leaf
+        for (size_t i = 0; i < nnodes; i++) {
+            if (!nodes[i].nPrims) continue;
+            nleaves++;
+            if (off + 2 + 3 * (size_t)nodes[i].nPrims > w.leafdata.size()) throw std::runtime_error("leaf data too short");
+            const flxw::F4 &h0 = w.leafdata[off], &h1 = w.leafdata[off + 1];
+            int cnt; memcpy(&cnt, &h0.w, 4);
+            if (cnt != nodes[i].nPrims || h0.x != nodes[i].bmin.x || h0.y != nodes[i].bmin.y || h0.z != nodes[i].bmin.z ||
+                h1.x != nodes[i].bmax.x || h1.y != nodes[i].bmax.y || h1.z != nodes[i].bmax.z) throw std::runtime_error("leaf header differs from the binary leaf");
+            for (uint32_t k = 0; k < nodes[i].nPrims; k++) {
+                const flxw::F4 &a = w.leafdata[off + 2 + 3 * k];
+                int ti; memcpy(&ti, &a.w, 4);
+                if ((uint32_t)ti != indices[nodes[i].iStartOrRight + k] || a.x != tris[ti].v0.p.x) throw std::runtime_error("leaf triangle order differs from the index list");
+            }
+            leafOfOffset[off] = (uint32_t)i;
+            off += 2 + 3 * (size_t)nodes[i].nPrims;
+        }
+        if (off != w.leafdata.size()) throw std::runtime_error("leaf data size");
+    }
+    uint64_t hist[5] = {0, 0, 0, 0, 0};
+    if (w.rootRef & FLX_WIDE_LEAF_BIT) { out8[0] = w.nodes.size(); out8[1] = w.leafdata.size(); out8[2] = w.maxStack; out8[3] = w.nested; out8[4] = nleaves; out8[5] = out8[6] = out8[7] = 0; return 0; }
+    // children are numbered after their parent, so one backwards sweep sees every child before its parent: exact[i] = union of the
+    // exact leaf boxes below wide node i, and every slot's REAL-arithmetic planes must enclose the exact box of what hangs there
+    std::vector<uint8_t> leafSeen(nnodes, 0), nodeSeen(w.nodes.size(), 0);
+    std::vector<Box> exact(w.nodes.size());
+    nodeSeen[0] = 1;
+    for (size_t wi = w.nodes.size(); wi-- > 0;) {
+        const flxw::WNode &n = w.nodes[wi];
+        const uint32_t refs[4] = {n.c0, n.c1, n.c2, n.c3};
+        const uint32_t ql[3] = {n.qlox, n.qloy, n.qloz}, qh[3] = {n.qhix, n.qhiy, n.qhiz};
+        const long double o[3] = {n.ox, n.oy, n.oz}, sc[3] = {n.sx, n.sy, n.sz};
+        int used = 0;
+        for (int c = 0; c < 4; c++) {
+            if (refs[c] == FLX_WIDE_EMPTY) {
+                for (int a = 0; a < 3; a++) if (((ql[a] >> (8 * c)) & 255u) != 255u || ((qh[a] >> (8 * c)) & 255u) != 0u) throw std::runtime_error("unused slot without an inverted box");
+                continue;
+            }
+            used++;
+            Box sub;
+            if (refs[c] & FLX_WIDE_LEAF_BIT) {
+                const uint32_t off = refs[c] & FLX_WIDE_OFF_MASK;
+                if (off >= leafOfOffset.size() || leafOfOffset[off] == 0xFFFFFFFFu) throw std::runtime_error("leaf ref does not point at a leaf block");
+                const uint32_t li = leafOfOffset[off];
+                if (leafSeen[li]++) throw std::runtime_error("leaf referenced twice");
+                sub.expand(&nodes[li].bmin.x); sub.expand(&nodes[li].bmax.x);
+            } else {
+                if (refs[c] >= w.nodes.size() || refs[c] <= wi) throw std::runtime_error("inner ref out of range or not after its parent");
+                if (nodeSeen[refs[c]]++) throw std::runtime_error("wide node referenced twice");
+                sub = exact[refs[c]];
+            }
+            for (int a = 0; a < 3; a++) {
+                const long double lo = o[a] + (long double)((ql[a] >> (8 * c)) & 255u) * sc[a], hi = o[a] + (long double)((qh[a] >> (8 * c)) & 255u) * sc[a];
+                if (lo > (long double)sub.mn[a] || hi < (long double)sub.mx[a]) throw std::runtime_error("quantised box does not contain the exact box of its subtree");
+            }
+            exact[wi].expand(sub);
+        }
+        if (used < 2) throw std::runtime_error("wide node with fewer than two children");
+        hist[used]++;
+        for (int a = 0; a < 3; a++) if ((long double)exact[wi].mn[a] < o[a]) throw std::runtime_error("grid origin above the subtree's min corner");
+    }
+    {   // the root's exact box is the binary root's
+        const flx_node &r = nodes[0];
+        if (exact[0].mn[0] != r.bmin.x || exact[0].mn[1] != r.bmin.y || exact[0].mn[2] != r.bmin.z || exact[0].mx[0] != r.bmax.x || exact[0].mx[1] != r.bmax.y || exact[0].mx[2] != r.bmax.z)
+            throw std::runtime_error("union of the leaf boxes differs from the binary root's box");
+    }
+    for (size_t i = 0; i < nnodes; i++) if (nodes[i].nPrims && leafSeen[i] != 1) throw std::runtime_error("binary leaf not referenced exactly once");
+    for (size_t i = 0; i < w.nodes.size(); i++) if (!nodeSeen[i]) throw std::runtime_error("wide node unreachable");
+    out8[0] = w.nodes.size(); out8[1] = w.leafdata.size(); out8[2] = w.maxStack; out8[3] = w.nested; out8[4] = nleaves;
+    out8[5] = hist[2]; out8[6] = hist[3]; out8[7] = hist[4];
     FH_CATCH
 }
 int fh_usable_threads() { return BVH::usableThreads(); }

@@ -76,6 +76,74 @@ def test_sbvh_parallel_build_is_the_serial_tree(gen, tris, seed):
         assert d.bvh_metrics == met, (threads, job)
 
 
+@pytest.mark.parametrize("gen,tris,seed,mode", [("kitchen", 30000, 42, "sbvh"), ("conference", 20000, 43, "sbvh"),
+                                                ("courtyard", 40000, 44, "binned"), ("kitchen", 3000, 7, "sah")])
+def test_wide_tree_invariants(gen, tris, seed, mode):
+    """The kernels' 4-wide quantised tree (csrc/flx_wide.h, built at flx_upload_scene from the reference-format binary tree) on the
+    CPU: conservative boxes in real arithmetic, each binary leaf exactly once with the leaf's exact box / count / triangle order (what
+    makes any-hit results identical and closest hits differ on ties only), each wide node once, and the SAH collapse fills the slots."""
+    d = host.generate_scene(gen, tris, seed)
+    host.build_bvh(d, mode)
+    info = host.wide_tree_check(d)
+    nleaf = int((d.nodes["nPrims"] > 0).sum())
+    assert info["leaves"] == nleaf
+    assert info["leaf_float4s"] == 5 + 2 * nleaf + 3 * d.indices.size
+    # k-ary tree with L leaves: (L - 1) / 3 <= wide nodes <= L - 1; the collapse should get close to the lower end
+    assert (nleaf - 1 + 2) // 3 <= info["wide_nodes"] <= nleaf - 1
+    assert info["wide_nodes"] <= 0.45 * nleaf
+    assert sum(info["slots_used"].values()) == info["wide_nodes"]
+    assert sum((k - 1) * v for k, v in info["slots_used"].items()) == nleaf - 1
+    depth = d.bvh_metrics["depth"]
+    assert 1 <= info["max_stack"] <= 3 * depth + 1
+
+
+def test_wide_tree_degenerate_inputs():
+    """One-leaf scene, a two-leaf tree, a maximally unbalanced chain, and malformed arrays (must be refused, not crash)."""
+    from fluctus_amd.wire import NODE
+    d = common.small_mesh_scene(n=2)
+    d.tris = d.tris[:3].copy()
+    host.build_bvh(d, "sah")
+    assert d.nodes.size == 1
+    info = host.wide_tree_check(d)
+    assert info["leaves"] == 1 and info["max_stack"] == 1
+    # chain: leaf i holds triangle i; inner nodes 0, 2, 4 ... each have {leaf, rest}
+    d = common.small_mesh_scene(n=4)
+    nt = 40
+    d.tris = d.tris[:nt].copy()
+    P = np.stack([np.stack([d.tris[v]["p"][a] for a in "xyz"], -1) for v in ("v0", "v1", "v2")], 1)       # (nt, 3 verts, 3)
+    tmin, tmax = P.min(1), P.max(1)
+    nodes = np.zeros(2 * nt - 1, NODE)
+    for k in range(nt - 1):                                      # inner node 2k: left leaf 2k+1 (tri k), right 2k+2
+        i = 2 * k
+        lo, hi = tmin[k:].min(0), tmax[k:].max(0)
+        for a, ax in enumerate("xyz"):
+            nodes[i]["bmin"][ax], nodes[i]["bmax"][ax] = lo[a], hi[a]
+            nodes[i + 1]["bmin"][ax], nodes[i + 1]["bmax"][ax] = tmin[k][a], tmax[k][a]
+        nodes[i]["iStartOrRight"] = i + 2
+        nodes[i + 1]["iStartOrRight"], nodes[i + 1]["nPrims"] = k, 1
+    last = 2 * nt - 2
+    for a, ax in enumerate("xyz"):
+        nodes[last]["bmin"][ax], nodes[last]["bmax"][ax] = tmin[nt - 1][a], tmax[nt - 1][a]
+    nodes[last]["iStartOrRight"], nodes[last]["nPrims"] = nt - 1, 1
+    d.nodes, d.indices = nodes, np.arange(nt, dtype=np.uint32)
+    info = host.wide_tree_check(d)
+    assert info["leaves"] == nt and info["wide_nodes"] == (nt - 1 + 2) // 3
+    # the nearest child can be the inner one at every level, leaving three leaves pending per wide node: the bound the spill buffer
+    # is sized from must cover that
+    assert info["max_stack"] == 3 * info["wide_nodes"] + 1
+    # malformed: right child pointing backwards, leaf range outside the index list, triangle index out of range
+    bad = nodes.copy(); bad[0]["iStartOrRight"] = 0
+    d.nodes = bad
+    with pytest.raises(Exception, match="child index"):
+        host.wide_tree_check(d)
+    d.nodes = nodes; d.indices = np.arange(nt - 1, dtype=np.uint32)
+    with pytest.raises(Exception, match="index list"):
+        host.wide_tree_check(d)
+    d.indices = np.arange(nt, dtype=np.uint32) + 1
+    with pytest.raises(Exception, match="triangle index"):
+        host.wide_tree_check(d)
+
+
 def test_sbvh_creates_duplicates_only_with_spatial_splits():
     d = host.generate_scene("conference", 20000, 43)
     host.build_bvh(d, "sbvh")
