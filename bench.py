@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--extend-tree", type=int, default=4, choices=(2, 4), help="tree flx_wf_extend walks: 4-wide quantised (default) or the reference's binary tree (bit-exact)")
     ap.add_argument("--shadow-tree", type=int, default=4, choices=(2, 4))
     ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--fuse", type=int, default=1, choices=(0, 1), help="logic + material kernels as one fused pass (default) or the separate kernels")
+    ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
@@ -201,7 +203,10 @@ def main():
         c_.set_option("overlap", args.overlap)
         c_.set_option("node_layout", args.node_layout)
         c_.set_option("eager_bump", args.eager_bump)
+        c_.set_option("fuse", args.fuse)
         c_.upload_scene(d)
+        if args.fuse_set:
+            c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene
         c_.upload_envmap(env)
         c_.set_partition(rank * C + i, world * C)
         c_.set_params(p)
@@ -420,7 +425,7 @@ def main():
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
                                     "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
-                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C,
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0,
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},

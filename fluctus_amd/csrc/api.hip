@@ -19,8 +19,10 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
-void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int);
+void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
+void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
+uint32_t fused_queue_mask(int);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
@@ -52,6 +54,15 @@ struct flx_ctx {
     bool logicChain = false, logicChainPrev = false;   // only raygen / materials / extend enqueued since flx_wf_logic
     int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic
     uint32_t *spill2 = nullptr;
+    // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
+    // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
+    // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
+    // settles the deferred calls first, so no call ever observes a state the separate kernels would not have produced.
+    int fuse = 1;
+    int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 3 + glossy | 31 all; chosen at flx_upload_scene
+    int pend = 0;                               // 0 nothing deferred | 1 flx_wf_logic | 2 flx_wf_logic, flx_wf_raygen
+    int pendFirst = 0;                          // the deferred flx_wf_logic's `first`
+    bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
     uint32_t numTasks = 0;
     std::string err;
     State st {};
@@ -175,7 +186,9 @@ extern "C" {
 
 // Every entry point that enqueues work or changes device state breaks the two "what came before" chains that let
 // flx_wf_shadow run ahead on the second stream; the few calls that are safe to run ahead of restore them (KEEP_CHAIN).
-#define MUTATES(c) do { (c)->overlapOK = false; (c)->logicChainPrev = (c)->logicChain; (c)->logicChain = false; } while (0)
+static int settle(flx_ctx *c);
+#define MUTATES_DEFERRING(c) do { (c)->overlapOK = false; (c)->logicChainPrev = (c)->logicChain; (c)->logicChain = false; } while (0)
+#define MUTATES(c) do { if (settle(c)) return 1; MUTATES_DEFERRING(c); } while (0)
 #define KEEP_CHAIN(c) do { (c)->logicChain = (c)->logicChainPrev; } while (0)
 // lazy extension counter (flx_device.h): make counters[EXTENSION] in memory current before anything outside the
 // raygen / material / extension / end-of-iteration kernels looks at it or overwrites the source counters
@@ -260,6 +273,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
 int flx_destroy(flx_ctx *c)
 {
     if (!c) return 0;
+    c->pend = 0;                                        // deferred kernels of a context that is going away: dropped
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { flx_group_destroy(c); }
@@ -293,6 +307,26 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     HIPCHK(c, hipSetDevice(c->device));
     const flx_triangle *tris = (const flx_triangle *)trisv;
     const flx_node *nodes = (const flx_node *)nodesv;
+
+    // 0. which BSDF types the fused logic+material pass inlines for this scene (logic.hip).  Inlining a type costs registers whether or not
+    // a path of that type shows up, routing a type through its queue costs a second trip over the path state: measured on the three bench
+    // scenes, a mostly-diffuse scene (kitchen 96 %, courtyard 65 % of the surface area) wants the diffuse step alone inline (+1..3 % Mrays/s
+    // over the separate kernels, inlining everything +-0), a scene whose surfaces are mostly glossy / GGX (conference: 13 % diffuse) wants
+    // them all (+11 %).  The reference specialises its kernels per scene too (-DBXDF_USE_*).  Option "fuse_set" overrides.
+    {
+        const flx_material *mats = (const flx_material *)materials;
+        double areaAll = 0.0, areaDiffuse = 0.0;
+        for (size_t i = 0; i < ntris; i++) {
+            const flx_triangle &t = tris[i];
+            const double ax = (double)t.v1.p.x - t.v0.p.x, ay = (double)t.v1.p.y - t.v0.p.y, az = (double)t.v1.p.z - t.v0.p.z;
+            const double bx = (double)t.v2.p.x - t.v0.p.x, by = (double)t.v2.p.y - t.v0.p.y, bz = (double)t.v2.p.z - t.v0.p.z;
+            const double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+            const double a = std::sqrt(cx * cx + cy * cy + cz * cz);
+            areaAll += a;
+            if (t.matId >= 0 && (size_t)t.matId < nmat && mats[t.matId].type == FLX_BXDF_DIFFUSE) areaDiffuse += a;
+        }
+        c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.5 * areaAll) ? 31 : 1;
+    }
 
     // 1. leaf triangle records, in index-list order (a leaf is a contiguous run of the list)
     std::vector<TriRec> trirecs(nidx);
@@ -493,7 +527,49 @@ int flx_wf_reset(flx_ctx *c) { READY(c); flushExt(c); { ScopedTimer t(c, FLX_K_R
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
 static void flushExtIfPending(flx_ctx *c, uint32_t bits) { if (c->qs.extPend & bits) flushExt(c); }
-int flx_wf_raygen(flx_ctx *c) { READY(c); KEEP_CHAIN(c); flushExtIfPending(c, 1u << FLX_Q_RAYGEN); { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); } c->qs.extPend |= 1u << FLX_Q_RAYGEN; if (c->eagerBump) flushExt(c); LAUNCHED(c); return 0; }
+static int runRaygen(flx_ctx *c)
+{
+    flushExtIfPending(c, 1u << FLX_Q_RAYGEN);
+    { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); }
+    c->qs.extPend |= 1u << FLX_Q_RAYGEN;
+    if (c->eagerBump) flushExt(c);
+    LAUNCHED(c);
+    return 0;
+}
+static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
+{
+    flushExt(c);                                       // logic's scan overwrites the source-queue counters
+    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst); }
+    LAUNCHED(c);
+    c->matQueuesEmpty = false;
+    if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
+    return 0;
+}
+static uint32_t materialBits(const flx_ctx *c)
+{
+    return c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
+}
+// launch what flx_wf_logic / flx_wf_raygen deferred, as the separate kernels (the caller is not flx_wf_materials)
+static int settle(flx_ctx *c)
+{
+    const int pd = c->pend;
+    if (!pd) return 0;
+    c->pend = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (runLogic(c, c->pendFirst, 0, 0)) return 1;
+    if (pd == 2 && runRaygen(c)) return 1;
+    return 0;
+}
+int flx_wf_raygen(flx_ctx *c)
+{
+    if (c->pend == 1) {                                // deferred behind the deferred flx_wf_logic (its queue does not exist yet)
+        MUTATES_DEFERRING(c); KEEP_CHAIN(c);
+        c->pend = 2;
+        return 0;
+    }
+    READY(c); KEEP_CHAIN(c);
+    return runRaygen(c);
+}
 int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
@@ -550,19 +626,45 @@ int flx_wf_shadow(flx_ctx *c)
 int flx_wf_logic(flx_ctx *c, int first)
 {
     READY(c);
-    flushExt(c);                                       // logic's scan overwrites the source-queue counters
-    { ScopedTimer t(c, FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first); }
-    LAUNCHED(c);
-    if (c->overlap == 2) { HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream)); c->logicChain = true; }
+    // fused with the material kernels if flx_wf_materials follows (see flx_ctx::fuse).  The fused scatter numbers the material
+    // queues from zero, so they must be empty now (cleared since the last logic: the reference clears all queues every iteration,
+    // src/tracer.cpp:255); otherwise, and with the option off, the kernel runs here and now.
+    const uint32_t allMat = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
+    // (with a single material queue every BSDF type sits in the diffuse list: only a pass that inlines them all can serve it)
+    const bool fusable = c->params.wfSeparateQueues || fused_queue_mask(c->fuseSet) == allMat;
+    if (c->fuse && c->matQueuesEmpty && fusable) { c->pend = 1; c->pendFirst = first; }
+    else if (runLogic(c, first, 0, 0)) return 1;
+    if (c->overlap == 2) c->logicChain = true;
     return 0;
 }
-int flx_wf_materials(flx_ctx *c) { READY(c); KEEP_CHAIN(c);
-    const uint32_t bits = c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
+int flx_wf_materials(flx_ctx *c)
+{
+    const int pd = c->pend;
+    if (pd) {
+        // [logic, materials] or [logic, raygen, materials]: one fused pass + scan + scatter, then the deferred genRays.  The
+        // extension-queue slots are the ones the separate kernels compute in the caller's order: with genRays first the material
+        // lists go behind the raygen queue, and genRays itself must not see them as pending yet.
+        c->pend = 0;
+        MUTATES_DEFERRING(c); KEEP_CHAIN(c);
+        NEED(c, c->haveParams && c->sc.bnodes, "set params and upload a scene first");
+        HIPCHK(c, hipSetDevice(c->device));
+        if (runLogic(c, c->pendFirst, c->fuseSet, pd == 2)) return 1;
+        if (pd == 2 && runRaygen(c)) return 1;
+        // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
+        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet)); }
+        LAUNCHED(c);
+        c->qs.extPend |= materialBits(c);
+        if (c->eagerBump) flushExt(c);
+        return 0;
+    }
+    READY(c); KEEP_CHAIN(c);
+    const uint32_t bits = materialBits(c);
     flushExtIfPending(c, bits);
     { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); }
     c->qs.extPend |= bits;
     if (c->eagerBump) flushExt(c);
-    LAUNCHED(c); return 0; }
+    LAUNCHED(c); return 0;
+}
 int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
 // ---- microkernel integrator.  One path per pixel, framebuffers indexed by the path id: single-GPU only, the pixel
@@ -587,11 +689,12 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
 }
 int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
-int flx_clear_queues(flx_ctx *c) { MUTATES(c); c->qs.extPend = 0; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+int flx_clear_queues(flx_ctx *c) { MUTATES(c); c->qs.extPend = 0; c->matQueuesEmpty = true; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
     NEED(c, out32, "flx_get_counters_async: null");
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     flushExt(c);
     if ((int)c->pending.size() >= c->pinnedSlots) { c->err = "too many outstanding counter reads; call flx_finish"; return 1; }
@@ -603,6 +706,7 @@ int flx_get_counters_async(flx_ctx *c, void *out32)
 
 int flx_finish(flx_ctx *c)
 {
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
@@ -643,11 +747,13 @@ int flx_end_iteration_async(flx_ctx *c)
     READY(c);
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend);
     c->qs.extPend = 0;
+    c->matQueuesEmpty = true;                           // it clears the queue counters
     LAUNCHED(c);
     return 0;
 }
 int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 {
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out8, c->totals, 64, hipMemcpyDeviceToHost, c->stream));
     if (reset) HIPCHK(c, hipMemsetAsync(c->totals, 0, 64, c->stream));
@@ -861,12 +967,13 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
 }
 
 // ---- measurement
-int flx_profile_enable(flx_ctx *c, int on) { c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
+int flx_profile_enable(flx_ctx *c, int on) { if (settle(c)) return 1; c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
 int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
 int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
-int flx_trace_stats_enable(flx_ctx *c, int on) { c->statsOn = on != 0; return 0; }
+int flx_trace_stats_enable(flx_ctx *c, int on) { if (settle(c)) return 1; c->statsOn = on != 0; return 0; }
 int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
 {
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out7, c->stats, 56, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -874,6 +981,7 @@ int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
 }
 int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
 {
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out16, c->stats, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -881,6 +989,7 @@ int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
 }
 int flx_trace_stats_get_all(flx_ctx *c, uint64_t *out24)
 {
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out24, c->stats, FLX_NUM_TRACE_STATS * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -918,6 +1027,7 @@ int flx_state_import(flx_ctx *c, const float *in)
 int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
 {
     NEED(c, q >= 0 && q < FLX_NUM_QUEUES, "bad queue id");
+    if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->qs.q[q], (size_t)c->numTasks * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -936,6 +1046,7 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 {
     MUTATES(c);
     c->qs.extPend = 0;                                  // the caller's counters are complete
+    c->matQueuesEmpty = false;                          // ... and unknown here
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->qs.counters, in32, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -943,7 +1054,10 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 }
 int flx_set_option(flx_ctx *c, const char *name, int value)
 {
+    if (settle(c)) return 1;
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
+    if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
+    if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->shadowTree = value; return 0; }
     if (name && strcmp(name, "extend_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->extendTree = value; return 0; }
@@ -955,6 +1069,16 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
+    return 1;
+}
+int flx_get_option(flx_ctx *c, const char *name, int *value)
+{
+    NEED(c, name && value, "flx_get_option: null");
+    const struct { const char *n; int v; } tab[] = {
+        {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+    for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
+    c->err = std::string("flx_get_option: unknown option ") + name;
     return 1;
 }
 

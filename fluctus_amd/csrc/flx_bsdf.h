@@ -370,4 +370,56 @@ __device__ __forceinline__ f3 bxdf_sample(const Scene &sc, const SurfHit &h, con
     return mk3(0.0f);
 }
 
+// ---- one path's material step (src/wf_mat_diffuse.cl:30-62 and twins): f and pdf toward the stored light direction (consumed by
+// `logic` next iteration), the continuation sample, the throughput update and the new ray.  Shared by the per-queue material kernels
+// (material.hip) and the fused logic+material kernel (logic.hip), so both run the same arithmetic in the same order.
+// USE = the BSDF types the caller can meet (the reference gets the same effect from -DBXDF_USE_* at OpenCL build time).
+enum { USE_DIFFUSE = 1, USE_GLOSSY = 2, USE_GGX_REFL = 4, USE_GGX_REFR = 8, USE_DELTA = 16, USE_ALL = 31 };
+
+struct MatStep {
+    f3 bsdfNEE; float bsdfPdfW;      // -> lastBsdf, lastPdfImplicit
+    f3 newT;                         // -> T
+    f3 orig; float pdfW;             // -> ray origin, lastPdfW
+    f3 newDir;                       // -> ray direction
+    uint32_t singular;               // -> lastSpecular
+};
+
+template <int USE>
+__device__ __forceinline__ MatStep material_step(const Scene &sc, const SurfHit &h, const flx_material &gm, bool backface, f3 dirIn, f3 L, f3 oldT, uint32_t *seed)
+{
+    Mat m; m.Kd = V(gm.Kd); m.Ks = V(gm.Ks); m.Ns = gm.Ns; m.Ni = gm.Ni; m.mapKd = gm.map_Kd; m.mapKs = gm.map_Ks; m.type = gm.type;
+    MatStep o;
+    // f and pdf toward the stored light direction (src/wf_mat_diffuse.cl:34-37)
+    f3 bsdfNEE = mk3(0.0f); float bsdfPdfW = 0.0f;
+    // continuation sample (:40-42)
+    float pdfW = 0.0f; f3 newDir = mk3(0.0f); f3 bsdf = mk3(0.0f);
+    if ((USE & USE_DIFFUSE) && m.type == FLX_BXDF_DIFFUSE) {
+        bsdfNEE = eval_diffuse(sc, h, m.Kd, m.mapKd); bsdfPdfW = pdf_diffuse(h, L);
+        bsdf = sample_diffuse(sc, h, m.Kd, m.mapKd, &newDir, &pdfW, seed);
+    } else if ((USE & USE_GLOSSY) && m.type == FLX_BXDF_GLOSSY) {
+        bsdfNEE = eval_glossy(sc, h, m, dirIn, L); bsdfPdfW = pdf_glossy(sc, h, m, dirIn, L);
+        bsdf = sample_glossy(sc, h, m, dirIn, &newDir, &pdfW, seed);
+    } else if ((USE & USE_GGX_REFL) && m.type == FLX_BXDF_GGX_ROUGH_REFLECTION) {
+        bsdfNEE = eval_ggx_reflect(sc, h, m.Ks, m.mapKs, m.Ns, m.Ni, dirIn, L); bsdfPdfW = pdf_ggx_reflect(h, m.Ns, dirIn, L);
+        bsdf = sample_ggx_reflect(sc, h, m.Ks, m.mapKs, m.Ns, m.Ni, dirIn, &newDir, &pdfW, seed);
+    } else if ((USE & USE_GGX_REFR) && m.type == FLX_BXDF_GGX_ROUGH_DIELECTRIC) {
+        bsdfNEE = eval_ggx_refract(sc, h, m, backface, dirIn, L); bsdfPdfW = pdf_ggx_refract(h, m, backface, dirIn, L);
+        bsdf = sample_ggx_refract(sc, h, m, backface, dirIn, &newDir, &pdfW, seed);
+    } else if ((USE & USE_DELTA) && m.type == FLX_BXDF_IDEAL_REFLECTION) {
+        bsdf = sample_ideal_reflection(sc, h, m, dirIn, &newDir, &pdfW);
+    } else if ((USE & USE_DELTA) && m.type == FLX_BXDF_IDEAL_DIELECTRIC) {
+        bsdf = sample_ideal_dielectric(sc, h, m, backface, dirIn, &newDir, &pdfW, seed);
+    }
+    o.bsdfNEE = bsdfNEE;
+    o.bsdfPdfW = fmaxf_(0.0f, bsdfPdfW);
+    const float costh = dot(h.N, normalize(newDir));
+    if (pdfW == 0.0f || is_zero(bsdf)) o.newT = mk3(0.0f);
+    else o.newT = oldT * bsdf * costh / pdfW;
+    o.orig = h.P + 1e-4f * newDir;                              // :53
+    o.pdfW = pdfW;
+    o.newDir = newDir;
+    o.singular = FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u;
+    return o;
+}
+
 } // namespace flxd

@@ -14,11 +14,28 @@
 // i.e. a STABLE compaction: queue order = ascending path id = the order sequential execution of
 // the reference produces.  Only the raygen queue's order is observable (pixel
 // assignment), and it makes device runs bit-reproducible.
-#include "flx_shading.h"
+//
+// FUSED = logic + the material kernels in one pass (flx_wf_logic ... flx_wf_materials with nothing but genRays between
+// them, see api.hip): a continuing path goes straight on to its material step (flx_bsdf.h: material_step, the code the
+// per-queue kernels run) with T, seed, hit record, normal and light direction still in registers -- the 96 B per path the
+// material kernels re-read and the 32 B both kernels write twice never travel.  Waves are no longer BSDF-uniform (the
+// reference's reason for the per-material queues), but the pass is bound by streaming the path state, not by the BSDF
+// arithmetic.  Queue contents, counters and the extension-queue order are the ones the separate kernels produce: the
+// scatter kernel appends the material lists to the extension queue at the slots the material kernels would compute.
+#include "flx_bsdf.h"
 
 namespace flxd {
 
 #define LOGIC_BLOCK 256
+// FUSE = the BSDF types the fused pass evaluates inline (0: none, the plain logic kernel); paths of the other types take the usual
+// route through their material queue and the `k_material_rest` kernel (material.hip).  Inlining costs registers for every type compiled
+// in (logic alone 68 VGPRs; + diffuse 94; + glossy 104; all six 106 and 4 waves/SIMD), so the host picks the set per scene from the
+// BSDF types its triangles use (api.hip) -- the reference specialises its kernels per scene the same way (-DBXDF_USE_*, src/clcontext.cpp).
+__host__ __device__ constexpr bool fuse_inlines_list(int fuse, uint32_t ml)     // ml = material_list(): 1 diffuse .. 5 delta
+{
+    return ml == 1u ? (fuse & USE_DIFFUSE) != 0 : ml == 2u ? (fuse & USE_GLOSSY) != 0 : ml == 3u ? (fuse & USE_GGX_REFL) != 0
+         : ml == 4u ? (fuse & USE_GGX_REFR) != 0 : ml == 5u ? (fuse & USE_DELTA) != 0 : false;
+}
 // membership byte: bit0 raygen, bit1 shadow, bits 2..4 material queue (0 none, 1 diffuse, 2 glossy,
 // 3 ggx reflection, 4 ggx refraction, 5 delta)
 #define NUM_LISTS 7   // raygen, shadow, 5 material
@@ -44,6 +61,7 @@ __device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
     }
 }
 
+template <int FUSE>
 __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, uint32_t firstIteration)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
@@ -153,6 +171,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             }
             wr4(st.at(S_HITN, gid), mk4u(hitN, (hflags & 1u) | (backface ? 2u : 0u)));   // :212-213
 
+            bool haveL = false; f3 Lnee = mk3(0.0f);                  // fused pass: this iteration's light direction, if NEE stores one
             if (p.sampleExpl && !FLX_BXDF_IS_SINGULAR(mat.type)) {    // next event estimation, :217-302
                 uint32_t den = p.useEnvMap + p.useAreaLight; if (den < 1u) den = 1u;
                 const float envMapProb = (float)p.useEnvMap / (float)den;
@@ -171,6 +190,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     st.pickProb[gid] = envMapProb;
                     eiw = __uint_as_float(pixIdx);
                     member |= 2u;
+                    haveL = true; Lnee = L;
                 }
                 if (useAreaLight) {
                     const float lightPickProb = 1.0f - envMapProb;
@@ -193,15 +213,31 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                         st.pickProb[gid] = lightPickProb;
                         eiw = __uint_as_float(pixIdx);
                         member |= 2u;
+                        haveL = true; Lnee = L;
                     } else {
                         st.blocked[gid] = 1u;
                     }
                 }
             }
             wr4(st.at(S_EI, gid), mk4(Ei, eiw));
-            wr4(st.at(S_THR, gid), mk4u(T, seed));
             (void)Tdirty;
-            member |= material_list(mat.type, p.wfSeparateQueues) << 2;
+            const uint32_t ml = material_list(mat.type, p.wfSeparateQueues);
+            member |= ml << 2;
+            if (FUSE != 0 && fuse_inlines_list(FUSE, ml)) {
+                // the material kernel's step for this path (material.hip: material_body), fed from registers.  The "stored light
+                // direction" is this iteration's sample when NEE stored one, else whatever the record holds (the material kernels
+                // evaluate toward it regardless, src/wf_mat_diffuse.cl:34-37; logic consumes the result only behind an unblocked ray)
+                const f3 L = haveL ? Lnee : ld3(rd4(st.at(S_SHD, gid)));
+                SurfHit h; h.P = hitP; h.N = hitN; h.uv = hitUV;
+                const MatStep o = material_step<FUSE>(sc, h, mat, backface, rayDir, L, T, &seed);
+                wr4(st.at(S_LBSDF, gid), mk4(o.bsdfNEE, o.bsdfPdfW));
+                wr4(st.at(S_LT, gid), mk4u(T, o.singular));
+                wr4(st.at(S_THR, gid), mk4u(o.newT, seed));
+                wr4(st.at(S_ORIG, gid), mk4(o.orig, o.pdfW));
+                wr4(st.at(S_DIR, gid), mk4u(o.newDir, len));               // pathLen without the FLX_FRESH flag, as the material kernels leave it
+            } else {
+                wr4(st.at(S_THR, gid), mk4u(T, seed));
+            }
         }
     }
 
@@ -257,8 +293,11 @@ __global__ __launch_bounds__(1024) void k_queue_scan(LogicAux aux, uint32_t *cou
     }
 }
 
-// stable scatter: rank within block by wave ballots, block base from the scan
-__global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicAux aux, uint32_t numTasks)
+// stable scatter: rank within block by wave ballots, block base from the scan.
+// FUSED: the material lists are also appended to the extension queue, at the slots the material kernels compute
+// (material.hip: extension base [+ the raygen queue when genRays was enqueued before the material kernels] + the material
+// queues before this one + own index).  Needs material queues that were empty before this `logic` (the host checks).
+__global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicAux aux, uint32_t numTasks, int fuse, uint32_t raygenFirst)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
     const uint32_t member = gid < numTasks ? aux.member[gid] : 0u;
@@ -280,19 +319,38 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
             for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w];
             r += mbcnt(bal[l]);
             outq[l][r] = gid;
+            if (fuse != 0 && l >= 2 && fuse_inlines_list(fuse, (uint32_t)(l - 1))) {
+                uint32_t base = ext_len(qs) + (raygenFirst ? qs.counters[FLX_Q_RAYGEN] : 0u);
+                for (int q = FLX_Q_DIFFUSE; q < FLX_Q_DIFFUSE + (l - 2); q++) base += qs.counters[q];
+                qs.q[FLX_Q_EXTENSION][base + r] = gid;
+            }
         }
     }
 }
 
+// queues (bit q) whose paths the fused pass takes through their material step
+uint32_t fused_queue_mask(int fuse)
+{
+    uint32_t m = 0;
+    for (uint32_t ml = 1; ml <= 5; ml++) if (fuse_inlines_list(fuse, ml)) m |= 1u << (FLX_Q_DIFFUSE + ml - 1);
+    return m;
+}
+
+// fuse: 0 = the plain logic kernel | USE_DIFFUSE | USE_ALL  (diffuse + glossy was measured too: never the best of the three)
 void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
-                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration)
+                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst)
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
     LogicAux aux{member, blockCounts, blockOffsets, blocks};
-    hipLaunchKernelGGL(k_logic, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+    const dim3 g(blocks), b(LOGIC_BLOCK);
+    switch (fuse) {
+    case USE_DIFFUSE: hipLaunchKernelGGL(k_logic<USE_DIFFUSE>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
+    case USE_ALL: hipLaunchKernelGGL(k_logic<USE_ALL>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
+    default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
+    }
     hipLaunchKernelGGL(k_queue_scan, dim3(NUM_LISTS), dim3(1024), 0, s, aux, qs.counters);
-    hipLaunchKernelGGL(k_queue_scatter, dim3(blocks), dim3(LOGIC_BLOCK), 0, s, qs, aux, st.numTasks);
+    hipLaunchKernelGGL(k_queue_scatter, g, b, 0, s, qs, aux, st.numTasks, fuse, (uint32_t)raygenFirst);
 }
 
 } // namespace flxd

@@ -19,8 +19,6 @@ namespace flxd {
 #define MAT_BLOCK 64            // one wave per block: interleaves best with the one-wave blocks of the concurrent shadow traversal (+1 %)
 #endif
 
-enum { USE_DIFFUSE = 1, USE_GLOSSY = 2, USE_GGX_REFL = 4, USE_GGX_REFR = 8, USE_DELTA = 16, USE_ALL = 31 };
-
 template <int USE>
 __device__ __forceinline__ void material_body(const State &st, const Queues &qs, const Scene &sc, int queueId, uint32_t idx, uint32_t earlierMask)
 {
@@ -38,44 +36,14 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
         uint32_t seed = __float_as_uint(thr.w);
         SurfHit h; h.P = ld3(hp); h.N = ld3(hn); h.uv = mk2(huv.x, huv.y);
         const bool backface = (__float_as_uint(hn.w) & 2u) != 0u;
-        const flx_material &gm = sc.materials[__float_as_int(huv.w)];
-        Mat m; m.Kd = V(gm.Kd); m.Ks = V(gm.Ks); m.Ns = gm.Ns; m.Ni = gm.Ni; m.mapKd = gm.map_Kd; m.mapKs = gm.map_Ks; m.type = gm.type;
-        const f3 dirIn = ld3(d4), L = ld3(sd);
-
-        // f and pdf toward the stored light direction (src/wf_mat_diffuse.cl:34-37)
-        f3 bsdfNEE = mk3(0.0f); float bsdfPdfW = 0.0f;
-        // continuation sample (:40-42)
-        float pdfW = 0.0f; f3 newDir = mk3(0.0f); f3 bsdf = mk3(0.0f);
-        if ((USE & USE_DIFFUSE) && m.type == FLX_BXDF_DIFFUSE) {
-            bsdfNEE = eval_diffuse(sc, h, m.Kd, m.mapKd); bsdfPdfW = pdf_diffuse(h, L);
-            bsdf = sample_diffuse(sc, h, m.Kd, m.mapKd, &newDir, &pdfW, &seed);
-        } else if ((USE & USE_GLOSSY) && m.type == FLX_BXDF_GLOSSY) {
-            bsdfNEE = eval_glossy(sc, h, m, dirIn, L); bsdfPdfW = pdf_glossy(sc, h, m, dirIn, L);
-            bsdf = sample_glossy(sc, h, m, dirIn, &newDir, &pdfW, &seed);
-        } else if ((USE & USE_GGX_REFL) && m.type == FLX_BXDF_GGX_ROUGH_REFLECTION) {
-            bsdfNEE = eval_ggx_reflect(sc, h, m.Ks, m.mapKs, m.Ns, m.Ni, dirIn, L); bsdfPdfW = pdf_ggx_reflect(h, m.Ns, dirIn, L);
-            bsdf = sample_ggx_reflect(sc, h, m.Ks, m.mapKs, m.Ns, m.Ni, dirIn, &newDir, &pdfW, &seed);
-        } else if ((USE & USE_GGX_REFR) && m.type == FLX_BXDF_GGX_ROUGH_DIELECTRIC) {
-            bsdfNEE = eval_ggx_refract(sc, h, m, backface, dirIn, L); bsdfPdfW = pdf_ggx_refract(h, m, backface, dirIn, L);
-            bsdf = sample_ggx_refract(sc, h, m, backface, dirIn, &newDir, &pdfW, &seed);
-        } else if ((USE & USE_DELTA) && m.type == FLX_BXDF_IDEAL_REFLECTION) {
-            bsdf = sample_ideal_reflection(sc, h, m, dirIn, &newDir, &pdfW);
-        } else if ((USE & USE_DELTA) && m.type == FLX_BXDF_IDEAL_DIELECTRIC) {
-            bsdf = sample_ideal_dielectric(sc, h, m, backface, dirIn, &newDir, &pdfW, &seed);
-        }
-        bsdfPdfW = fmaxf_(0.0f, bsdfPdfW);
-        const float costh = dot(h.N, normalize(newDir));
         const f3 oldT = ld3(thr);
-        f3 newT;
-        if (pdfW == 0.0f || is_zero(bsdf)) newT = mk3(0.0f);
-        else newT = oldT * bsdf * costh / pdfW;
-        const f3 orig = h.P + 1e-4f * newDir;                      // :53
+        const MatStep o = material_step<USE>(sc, h, sc.materials[__float_as_int(huv.w)], backface, ld3(d4), ld3(sd), oldT, &seed);
 
-        wr4(st.at(S_LBSDF, gid), mk4(bsdfNEE, bsdfPdfW));
-        wr4(st.at(S_LT, gid), mk4u(oldT, FLX_BXDF_IS_SINGULAR(m.type) ? 1u : 0u));
-        wr4(st.at(S_THR, gid), mk4u(newT, seed));
-        wr4(st.at(S_ORIG, gid), mk4(orig, pdfW));
-        wr4(st.at(S_DIR, gid), mk4u(newDir, __float_as_uint(d4.w) & ~FLX_FRESH));   // pathLen; "no material kernel since regeneration" ends here
+        wr4(st.at(S_LBSDF, gid), mk4(o.bsdfNEE, o.bsdfPdfW));
+        wr4(st.at(S_LT, gid), mk4u(oldT, o.singular));
+        wr4(st.at(S_THR, gid), mk4u(o.newT, seed));
+        wr4(st.at(S_ORIG, gid), mk4(o.orig, o.pdfW));
+        wr4(st.at(S_DIR, gid), mk4u(o.newDir, __float_as_uint(d4.w) & ~FLX_FRESH));   // pathLen; "no material kernel since regeneration" ends here
     }
     if (active) {
         // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)
@@ -94,12 +62,13 @@ __global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Sce
 // The four small queues (glossy, GGX reflection, GGX refraction, delta) in ONE launch: each block serves one queue
 // (block ranges follow the queue lengths), so waves stay BSDF-uniform like in the per-queue kernels, but three
 // near-empty 4096-block launches per iteration disappear.
-__global__ __launch_bounds__(MAT_BLOCK) void k_material_rest(State st, Queues qs, Scene sc)
+// doneMask: queues the fused logic pass has already served (logic.hip); they only count as "appended earlier".
+__global__ __launch_bounds__(MAT_BLOCK) void k_material_rest(State st, Queues qs, Scene sc, uint32_t doneMask)
 {
     uint32_t b = blockIdx.x;
     uint32_t earlier = 1u << FLX_Q_DIFFUSE;
     for (int q = FLX_Q_GLOSSY; q <= FLX_Q_DELTA; q++) {
-        const uint32_t nb = (qs.counters[q] + MAT_BLOCK - 1) / MAT_BLOCK;
+        const uint32_t nb = (doneMask & (1u << q)) ? 0u : (qs.counters[q] + MAT_BLOCK - 1) / MAT_BLOCK;
         if (b < nb) { material_body<USE_GLOSSY | USE_GGX_REFL | USE_GGX_REFR | USE_DELTA>(st, qs, sc, q, b * MAT_BLOCK + threadIdx.x, earlier); return; }
         b -= nb;
         earlier |= 1u << q;
@@ -129,11 +98,23 @@ void launch_materials(hipStream_t s, const State &st, const Queues &qs, const Sc
         launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, 0u);
         {   // glossy + ggxRefl + ggxRefr + delta (at most numTasks paths in total -> blocks + 4 partial blocks)
             uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK + 4;
-            hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc);
+            hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, 0u);
         }
         (void)G; (void)RL; (void)RR; (void)DL; (void)D;            // the host records the appended queues (flx_wf_materials): lazy bump
     } else {
         launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_ALL, 0u);
+    }
+}
+
+// what is left of flx_wf_materials after the fused logic pass (separate queues): the queues in doneMask are served already
+void launch_materials_after_fused(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, uint32_t doneMask)
+{
+    const uint32_t all = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
+    if ((doneMask & all) == all) return;
+    if (!(doneMask & (1u << FLX_Q_DIFFUSE))) launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, 0u);
+    if ((doneMask & (all & ~(1u << FLX_Q_DIFFUSE))) != (all & ~(1u << FLX_Q_DIFFUSE))) {
+        uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK + 4;
+        hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, doneMask);
     }
 }
 

@@ -20,10 +20,10 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_group_unique_id", "flx_group_init", "flx_group_init_local", "flx_gather", "flx_gather_local", "flx_group_destroy", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
-           "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
+           "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_get_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
-KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7}
+KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7, "logic_fused": 8}
 
 
 def _preload_torch_runtime():
@@ -240,6 +240,11 @@ class HipContext:
         return dict(ext={n: int(out[8 + i]) for i, n in enumerate(k)}, shadow={n: int(out[12 + i]) for i, n in enumerate(k)}, ext_max_inner_sum=int(out[7]))
 
     def set_option(self, name, value): self._chk(self.L.flx_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._chk(self.L.flx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
 
 def group_unique_id():

@@ -146,7 +146,8 @@ int flx_group_destroy(flx_ctx *ctx);
 enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FLX_K_LOGIC = 4, FLX_K_MATERIALS = 5,
        FLX_K_POSTPROCESS = 6,
        FLX_K_TRACE_SPAN = 7,   /* start of the extension kernel .. end of the (concurrent) shadow kernel */
-       FLX_K_COUNT = 8 };
+       FLX_K_LOGIC_FUSED = 8,  /* logic + the inlined material step as one pass (option "fuse"); FLX_K_MATERIALS then covers the rest */
+       FLX_K_COUNT = 9 };
 /* on: 0 off | 1 time every kernel | 2 time only the two trace kernels (+ their span), as the reference does | 3 only the
  * extension kernel.  Each event pair costs a few microseconds of stream time, which shows at ~11 launches per 0.7 ms
  * iteration: level 1 costs 7 % of the throughput, level 3 about 1.5 %. */
@@ -188,10 +189,23 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *   overlap           0 serial | 1 flx_wf_shadow directly after flx_wf_extend runs concurrently with it on a second stream |
  *                     2 (default) as 1, and it starts as soon as `logic` is done when only raygen / materials / extend
  *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip)
+ *   fuse              1 (default): flx_wf_logic is DEFERRED -- launched by the next call on this context; when that call is
+ *                     flx_wf_materials (a flx_wf_raygen between the two is deferred along and launched right after), logic and the
+ *                     material step of the most common BSDF types run as ONE pass over the path state (logic.hip: k_logic<FUSED>),
+ *                     the other types through their queues as usual; when it is anything else, the plain kernel runs first.  No call
+ *                     can observe a state, queue or counter the separate kernels would not have produced (the extension queue keeps
+ *                     their order); an error raised by a deferred launch is reported by the call that launched it.  Needs the
+ *                     material queues empty (flx_clear_queues / flx_end_iteration_async since the last logic) and wfSeparateQueues
+ *                     (or a build that inlines every type) -- otherwise, and with 0, every call launches its own kernels at once
+ *   fuse_set          BSDF types the fused pass inlines: 1 diffuse only | 31 all six.  flx_upload_scene picks it from the scene
+ *                     (diffuse surfaces >= half of the triangle area: 1, else 31); set it after the upload to override
  *   node_layout       1 (default) sibling-pair record numbering of the binary tree | 0 DFS numbering; takes effect at the next flx_upload_scene
  *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
  *   xcd_remap, eager_bump: A/B knobs of the binary kernels */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
+/* current value of an option above, or of the read-only "fused_queue_mask" (bit q set = the fused pass inlines the material step of
+ * queue q's paths, flx_queue_counters order) */
+int flx_get_option(flx_ctx *ctx, const char *name, int *value);
 
 #ifdef __cplusplus
 }

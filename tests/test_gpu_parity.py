@@ -15,16 +15,22 @@ from fluctus_amd import host, wire, driver
 pytestmark = pytest.mark.gpu
 
 
-TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2}
+TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_set": 0}
 
 
 # (extend_tree, shadow_tree, xcd_remap, overlap): every tree / stream schedule that claims bit-exactness must give the same bits.
 # extend_tree is 2 throughout (the reference's visit order); the 4-wide closest-hit kernel is order-dependent in exact ties and
 # has its own tests with a flip count (tests/test_gpu_wide.py).  shadow_tree 4 (the default) is exact by construction.
-@pytest.fixture(params=[(2, 4, 0, 2), (2, 2, 1, 1), (2, 2, 0, 0), (2, 4, 0, 0), (2, 4, 0, 1)],
-                ids=["wide-shadow", "binary-shadow-xcdremap-overlap1", "binary-shadow-serial", "wide-shadow-serial", "wide-shadow-overlap1"], autouse=True)
+# fuse: logic + material kernels as one pass whenever flx_wf_materials follows flx_wf_logic with at most genRays between them (the
+# default; api.hip) vs always the separate kernels.
+# fuse_set: the BSDF types that pass inlines -- 0 = what flx_upload_scene picked for the scene, 1 diffuse only (the rest through their
+# queues), 31 all.
+@pytest.fixture(params=[(2, 4, 0, 2, 1, 0), (2, 2, 1, 1, 1, 31), (2, 2, 0, 0, 0, 0), (2, 4, 0, 0, 1, 1), (2, 4, 0, 1, 0, 0)],
+                ids=["wide-shadow", "binary-shadow-xcdremap-overlap1-fuseall", "binary-shadow-serial-unfused", "wide-shadow-serial-fusediffuse",
+                     "wide-shadow-overlap1-unfused"], autouse=True)
 def trace_mode(request):
-    TRACE_MODE["ext"], TRACE_MODE["shadow"], TRACE_MODE["xcd"], TRACE_MODE["overlap"] = request.param
+    (TRACE_MODE["ext"], TRACE_MODE["shadow"], TRACE_MODE["xcd"], TRACE_MODE["overlap"], TRACE_MODE["fuse"],
+     TRACE_MODE["fuse_set"]) = request.param
     yield
 
 
@@ -36,12 +42,15 @@ def _ctxs(d, p, n, env=None):
     g.set_option("shadow_tree", TRACE_MODE["shadow"])
     g.set_option("overlap", TRACE_MODE["overlap"])
     g.set_option("xcd_remap", TRACE_MODE["xcd"])
+    g.set_option("fuse", TRACE_MODE["fuse"])
     for c in (g, o):
         c.upload_scene(d)
         if env is not None:
             c.upload_envmap(env)
         c.set_params(p)
         driver.reset_renderer(c)
+    if TRACE_MODE["fuse_set"]:
+        g.set_option("fuse_set", TRACE_MODE["fuse_set"])          # after the upload, which picks one for the scene
     return g, o
 
 
@@ -76,6 +85,35 @@ def _lockstep(g, o, npix, iters):
             c.pixel_index_update(npix, int(cnt[0]))
 
 
+def _lockstep_iterations(g, o, npix, iters, order=("logic", "raygen", "materials"), separate_queues=1):
+    """Whole-iteration lockstep: logic / genRays / materials enqueued back to back as the reference's host does
+    (src/tracer.cpp:245-249), which is when the device runs logic and the material kernels as ONE fused pass (api.hip); state,
+    counters and every queue -- the extension queue's order included -- compared after the three calls, then after the two
+    traversals.  `_lockstep` above looks at the state after every single call and therefore always gets the separate kernels."""
+    fns = {"logic": lambda c: c.wf_logic(False), "raygen": lambda c: c.wf_raygen(), "materials": lambda c: c.wf_materials()}
+    g.profile_enable(1); g.profile_reset()
+    for it in range(iters):
+        common.sync(g, o)
+        for c in (g, o):
+            c.clear_queues()                        # the state sync above rewrote the counters: the queues are empty, say so
+            for name in order:
+                fns[name](c)
+        _compare(g, o, f"it{it} {'+'.join(order)}")
+        cnt = o.get_counters().copy()
+        for c in (g, o):
+            c.wf_extend(); c.wf_shadow()
+        _compare(g, o, f"it{it} extend+shadow")
+        for c in (g, o):
+            c.clear_queues()
+            c.pixel_index_update(npix, int(cnt[0]))
+    g.finish()
+    prof = g.profile_get()
+    g.profile_enable(0)
+    # the fused pass is what ran (with separate queues, or when it inlines every BSDF type; never with the option off)
+    fused = TRACE_MODE["fuse"] and (separate_queues or g.get_option("fused_queue_mask") == 0xF8)
+    assert prof["logic_fused"][1] == (iters if fused else 0) and prof["logic"][1] == (0 if fused else iters), prof
+
+
 def _free_run(g, o, npix, iters):
     for it in range(iters):
         cg = driver.benchmark_iteration(g, npix)
@@ -96,6 +134,7 @@ def test_lockstep_simple_area_light():
     p = common.scene_params(d, w, h, maxBounces=4)
     g, o = _ctxs(d, p, n)
     _lockstep(g, o, w * h, 6)
+    _lockstep_iterations(g, o, w * h, 4, separate_queues=int(p["wfSeparateQueues"]))
 
 
 @pytest.mark.parametrize("area,env,expl,impl,sep,roulette", [
@@ -107,6 +146,8 @@ def test_lockstep_all_bsdfs_flag_matrix(area, env, expl, impl, sep, roulette):
                             wfSeparateQueues=sep, useRoulette=roulette, envMapStrength=1.5)
     g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
     _lockstep(g, o, w * h, 7)
+    _lockstep_iterations(g, o, w * h, 5, separate_queues=sep)
+    _lockstep_iterations(g, o, w * h, 3, order=("logic", "materials", "raygen"), separate_queues=sep)
 
 
 @pytest.mark.parametrize("sep", [0, 1])
