@@ -278,6 +278,16 @@ def main():
             if not prof.get(k, (0.0, 0))[1]:
                 prof[k] = v; untimed.append(k)
         ctx.counter_totals(reset=True)
+    # the extension kernel WITHOUT the concurrent shadow traversal (serial schedule), untimed: in the timed region the two share the
+    # machine and the event-timed duration of either depends on how the hardware splits it between them
+    ctx.set_option("overlap", 0)
+    ctx.profile_reset(); ctx.profile_enable(3)
+    for _ in range(12):
+        step_async(ctx)
+    ctx.finish(); ctx.profile_enable(0)
+    alone_ms, alone_n = ctx.profile_get()["extend"]
+    ctx.set_option("overlap", args.overlap)
+    ctx.counter_totals(reset=True)
     rays_local = float(tot[1]) + float(tot[2])
     elapsed = t1 - t0
     if use_dist:
@@ -434,7 +444,7 @@ def main():
             "roofline": {"kernel": "traceExtension (k_extend4: 4-wide quantised tree)" if args.extend_tree == 4 else "traceExtension (k_extend: binary tree)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "definition": "achieved = SURVEY 8(d) algorithmic bytes of the REFERENCE traversal (84 + 64 n_inner + 40 n_tri + 64 [hit] per ray, binary tree, "
+                         "definition": "launch_ms / frac: the kernel as it runs in the timed region, sharing the machine with the concurrent shadow traversal (two streams); launch_ms_alone / frac_alone: the same kernel on the same steady state with the serial schedule (untimed extra pass).  achieved = SURVEY 8(d) algorithmic bytes of the REFERENCE traversal (84 + 64 n_inner + 40 n_tri + 64 [hit] per ray, binary tree, "
                                        "near child first; counted on the same rays) x rays per launch / HIP-event launch time.  These bytes are served by L2 / Infinity "
                                        "Cache for this scene: frac_traffic is the fabric-side counter traffic over the same time, frac_own the bytes the running kernel touches",
                          "frac_traffic": (traffic / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ext_ms > 0) else None,
@@ -447,7 +457,10 @@ def main():
                          "avg_inner_visits": st["ext_inner"] / max(1, st["ext_rays"]),
                          "avg_tri_tests": st["ext_tri"] / max(1, st["ext_rays"]),
                          "hit_fraction": st["ext_hits"] / max(1, st["ext_rays"]),
-                         "launch_ms": ext_ms / max(1, ext_n), "simd_efficiency": simd,
+                         "launch_ms": ext_ms / max(1, ext_n),
+                         "launch_ms_alone": alone_ms / max(1, alone_n),
+                         "frac_alone": (achieved * (ext_ms / max(1, ext_n)) / (alone_ms / max(1, alone_n)) / 8000.0) if alone_ms > 0 and ext_ms > 0 else None,
+                         "simd_efficiency": simd,
                          "note": "k_extend runs concurrently with k_shadow (two streams); 'concurrent_traversal' = (extension + shadow "
                                  "algorithmic bytes) / span of the pair",
                          "concurrent_traversal": ({"achieved": combined, "frac": combined / HBM_PEAK_GBS, "span_ms": span_ms / span_n,

@@ -207,6 +207,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     c->device = device; c->numTasks = num_tasks;
     auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    // (stream priorities were tried: a high-priority shadow stream keeps the extension kernel at its undisturbed 0.86 ms and inflates
+    //  the material kernel instead, a high-priority main stream changes nothing -- resident waves are not displaced; the step time
+    //  stays within 0.7 % in every combination, so both streams have the default priority)
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess ||

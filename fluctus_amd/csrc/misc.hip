@@ -51,11 +51,9 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame
 __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p)
 {
     const uint32_t qlen = qs.counters[FLX_Q_RAYGEN];
-    const uint32_t gd = blockIdx.x * MISC_BLOCK + threadIdx.x;
-    const bool active = gd < qlen;
-    uint32_t gid = 0;
-    if (active) {
-        gid = qs.q[FLX_Q_RAYGEN][gd];
+    // capped grid striding over the queue (its length is only known here; see MAT_GRID in material.hip)
+    for (uint32_t gd = blockIdx.x * MISC_BLOCK + threadIdx.x; gd < qlen; gd += gridDim.x * MISC_BLOCK) {
+        const uint32_t gid = qs.q[FLX_Q_RAYGEN][gd];
         uint32_t seed = __float_as_uint(rd4(st.at(S_THR, gid)).w);
         // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
         // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
@@ -91,8 +89,8 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         st.pickProb[gid] = 1.0f;                                       // read by the MIS weights before any NEE may have written it
         st.blocked[gid] = 1u;
         st.firstDiffuse[gid] = 0u;
+        qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;              // extBase + index (see flx_device.h)
     }
-    if (active) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;   // extBase + index (see flx_device.h)
 }
 
 __global__ void k_bump_extension(uint32_t *counters, uint32_t srcMask)
@@ -238,7 +236,9 @@ void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame 
 }
 void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
 {
-    hipLaunchKernelGGL(k_raygen, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
+    uint32_t blocks = (st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
 }
 void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
 {

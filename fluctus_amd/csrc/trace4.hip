@@ -57,7 +57,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_MIN_WAVES) void k_extend4(State st
     }
 }
 
-template <bool STATS>
+template <bool STATS, int ANY_ORDER>
 __global__ __launch_bounds__(WIDE_BLOCK, WIDE_MIN_WAVES) void k_shadow4(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_MIN_WAVES) void k_shadow4(State st
     if (p.useAreaLight) { float tl = lenL; occluded = light_quad(p.areaLight, orig, dir, &tl); }
     if (!occluded) {
         float t = lenL, u, v; int tri;
-        occluded = traverse4<true, STATS>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri, nLeaf, STATS ? aux.stats + 12 : nullptr);
+        occluded = traverse4<true, STATS, ANY_ORDER>(sc, stk, orig, dir, t, u, v, tri, nInner, nTri, nLeaf, STATS ? aux.stats + 12 : nullptr);
     }
     st.blocked[gid] = occluded ? 1u : 0u;
 
@@ -111,8 +111,15 @@ void launch_shadow4(hipStream_t s, const State &st, const Queues &qs, const Scen
 {
     uint32_t blocks = (st.numTasks + WIDE_BLOCK - 1) / WIDE_BLOCK;
     TraceAux aux{spill, blocks * WIDE_BLOCK, stats};
-    if (stats) hipLaunchKernelGGL(k_shadow4<true>, dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
-    else hipLaunchKernelGGL(k_shadow4<false>, dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
+    // visit order of the any-hit traversal (flx_trace4.h: ANY_ORDER): far -> near when every shadow ray runs toward the environment light
+    const bool farFirst = p.useEnvMap && !p.useAreaLight;
+    if (stats) {
+        if (farFirst) hipLaunchKernelGGL((k_shadow4<true, 1>), dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
+        else hipLaunchKernelGGL((k_shadow4<true, 0>), dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
+    } else {
+        if (farFirst) hipLaunchKernelGGL((k_shadow4<false, 1>), dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
+        else hipLaunchKernelGGL((k_shadow4<false, 0>), dim3(blocks), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux);
+    }
 }
 
 } // namespace flxd

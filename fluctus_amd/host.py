@@ -135,9 +135,10 @@ def wide_tree_check(d):
     invariants: conservative quantised boxes, every binary leaf exactly once with its box / count / triangle order, every wide node
     reachable once, unused slots inverted.  Raises on a violation; returns the tree's figures."""
     out = (C.c_uint64 * 8)()
-    _chk(lib().fh_wide_tree_check(_p(d.nodes), C.c_uint64(d.nodes.size), _p(d.tris), C.c_uint64(d.tris.size),
-                                  _p(d.indices), C.c_uint64(d.indices.size), out))
-    return dict(wide_nodes=out[0], leaf_float4s=out[1], max_stack=out[2], nested=bool(out[3]), leaves=out[4],
+    areas = (C.c_double * 2)()
+    _chk(lib().fh_wide_tree_areas(_p(d.nodes), C.c_uint64(d.nodes.size), _p(d.tris), C.c_uint64(d.tris.size),
+                                  _p(d.indices), C.c_uint64(d.indices.size), out, areas))
+    return dict(area_exact=areas[0], area_quantised=areas[1], wide_nodes=out[0], leaf_float4s=out[1], max_stack=out[2], nested=bool(out[3]), leaves=out[4],
                 slots_used={2: out[5], 3: out[6], 4: out[7]})
 
 

@@ -108,9 +108,21 @@ int fh_bvh_build_ex(const void *tris, uint64_t ntris, int mode, int threads, uin
 //  block carries the leaf's box, count and triangles, every inner record is referenced exactly once, unused slots point at the dummy
 //  leaf.  out8 = {wide nodes, leaf data float4s, stack bound, nested, leaves, max children per node histogram packed: [5]=2-slot nodes,
 //  [6]=3-slot, [7]=4-slot}.
+static int wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, uint64_t ntris, const uint32_t *indices, uint64_t nidx, uint64_t *out8, double *areas2);
 int fh_wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, uint64_t ntris, const uint32_t *indices, uint64_t nidx, uint64_t *out8)
 {
+    return wide_tree_check(nodesv, nnodes, trisv, ntris, indices, nidx, out8, nullptr);
+}
+// + areas2 = {sum of the EXACT surface areas of everything a wide-node slot refers to, sum of the slots' QUANTISED box areas}: their ratio
+// is what the 8-bit boxes cost in expected visits (surface-area heuristic)
+int fh_wide_tree_areas(const void *nodesv, uint64_t nnodes, const void *trisv, uint64_t ntris, const uint32_t *indices, uint64_t nidx, uint64_t *out8, double *areas2)
+{
+    return wide_tree_check(nodesv, nnodes, trisv, ntris, indices, nidx, out8, areas2);
+}
+static int wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, uint64_t ntris, const uint32_t *indices, uint64_t nidx, uint64_t *out8, double *areas2)
+{
     FH_TRY
+    double areaExact = 0.0, areaQuant = 0.0;
     const flx_node *nodes = (const flx_node *)nodesv;
     const flx_triangle *tris = (const flx_triangle *)trisv;
     flxw::WideTree w; const char *err = nullptr;
@@ -173,6 +185,13 @@ int fh_wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, u
                 const long double lo = o[a] + (long double)((ql[a] >> (8 * c)) & 255u) * sc[a], hi = o[a] + (long double)((qh[a] >> (8 * c)) & 255u) * sc[a];
                 if (lo > (long double)sub.mn[a] || hi < (long double)sub.mx[a]) throw std::runtime_error("quantised box does not contain the exact box of its subtree");
             }
+            {
+                double q[3];
+                for (int a = 0; a < 3; a++) q[a] = (double)(((qh[a] >> (8 * c)) & 255u) - (long double)((ql[a] >> (8 * c)) & 255u)) * (double)sc[a];
+                areaQuant += q[0] * q[1] + q[1] * q[2] + q[2] * q[0];
+                const double e0 = (double)sub.mx[0] - sub.mn[0], e1 = (double)sub.mx[1] - sub.mn[1], e2 = (double)sub.mx[2] - sub.mn[2];
+                areaExact += e0 * e1 + e1 * e2 + e2 * e0;
+            }
             exact[wi].expand(sub);
         }
         if (used < 2) throw std::runtime_error("wide node with fewer than two children");
@@ -188,6 +207,7 @@ int fh_wide_tree_check(const void *nodesv, uint64_t nnodes, const void *trisv, u
     for (size_t i = 0; i < w.nodes.size(); i++) if (!nodeSeen[i]) throw std::runtime_error("wide node unreachable");
     out8[0] = w.nodes.size(); out8[1] = w.leafdata.size(); out8[2] = w.maxStack; out8[3] = w.nested; out8[4] = nleaves;
     out8[5] = hist[2]; out8[6] = hist[3]; out8[7] = hist[4];
+    if (areas2) { areas2[0] = areaExact; areas2[1] = areaQuant; }
     FH_CATCH
 }
 int fh_usable_threads() { return BVH::usableThreads(); }

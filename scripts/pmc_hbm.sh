@@ -18,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        for key in ("k_extend4<false>", "k_shadow4<false>", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material<1>", "k_material_rest", "k_raygen", "k_queue_scatter"):
+        for key in ("k_extend4<false>", "k_shadow4<false", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material<1>", "k_material_rest", "k_raygen", "k_queue_scatter"):
             if key in k:
                 a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(acc):

@@ -15,8 +15,10 @@ def short(name):
         if k in n:
             if k == "k_material":
                 return n[n.find("k_material"):][:24]
+            if k == "k_logic":
+                return n[n.find("k_logic"):][:24]          # k_logic<0> plain | <1> diffuse step inline | <31> every BSDF inline
             if k in ("k_extend4", "k_shadow4", "k_extend", "k_shadow"):
-                return k + ("<STATS>" if "<true>" in name or "ILb1E" in name else "")
+                return k + ("<STATS>" if "<true" in name or "ILb1E" in name else "")
             return k
     return n[:40]
 
