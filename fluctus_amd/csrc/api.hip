@@ -592,7 +592,7 @@ int flx_wf_shadow(flx_ctx *c)
 {
     // The shadow kernel touches {shadowOrig, shadowDir, shadow queue} -> shadowRayBlocked, the extension kernel
     // {orig, dir, extension queue} -> hit + pathLen: disjoint.  When it directly follows flx_wf_extend (the reference's
-    // order, src/tracer.cpp:250-251) it is launched on a second stream that only waits for the work enqueued BEFORE the
+    // order, src/tracer.cpp:253-254) it is launched on a second stream that only waits for the work enqueued BEFORE the
     // extension kernel, so the two traversals share the machine and fill each other's tails; the main stream then waits
     // for it, which keeps the single-in-order-queue semantics for everything that follows.
     // overlap 2: its inputs are complete when `logic` is (NEE lives there, src/wf_logic.cl:217-302).  What the reference
@@ -631,7 +631,7 @@ int flx_wf_logic(flx_ctx *c, int first)
     READY(c);
     // fused with the material kernels if flx_wf_materials follows (see flx_ctx::fuse).  The fused scatter numbers the material
     // queues from zero, so they must be empty now (cleared since the last logic: the reference clears all queues every iteration,
-    // src/tracer.cpp:255); otherwise, and with the option off, the kernel runs here and now.
+    // src/tracer.cpp:257); otherwise, and with the option off, the kernel runs here and now.
     const uint32_t allMat = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
     // (with a single material queue every BSDF type sits in the diffuse list: only a pass that inlines them all can serve it)
     const bool fusable = c->params.wfSeparateQueues || fused_queue_mask(c->fuseSet) == allMat;

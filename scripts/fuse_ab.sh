@@ -20,5 +20,5 @@ for l in sys.stdin:
 }
 for rep in 1 2; do
   run unfused --fuse 0 "$@"
-  for v in 1 3 31; do run set$v --fuse 1 --fuse-set $v "$@"; done
+  for v in 1 31; do run set$v --fuse 1 --fuse-set $v "$@"; done
 done

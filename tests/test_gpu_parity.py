@@ -87,7 +87,7 @@ def _lockstep(g, o, npix, iters):
 
 def _lockstep_iterations(g, o, npix, iters, order=("logic", "raygen", "materials"), separate_queues=1):
     """Whole-iteration lockstep: logic / genRays / materials enqueued back to back as the reference's host does
-    (src/tracer.cpp:245-249), which is when the device runs logic and the material kernels as ONE fused pass (api.hip); state,
+    (src/tracer.cpp:247-251), which is when the device runs logic and the material kernels as ONE fused pass (api.hip); state,
     counters and every queue -- the extension queue's order included -- compared after the three calls, then after the two
     traversals.  `_lockstep` above looks at the state after every single call and therefore always gets the separate kernels."""
     fns = {"logic": lambda c: c.wf_logic(False), "raygen": lambda c: c.wf_raygen(), "materials": lambda c: c.wf_materials()}
