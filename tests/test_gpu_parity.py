@@ -150,6 +150,49 @@ def test_lockstep_all_bsdfs_flag_matrix(area, env, expl, impl, sep, roulette):
     _lockstep_iterations(g, o, w * h, 3, order=("logic", "materials", "raygen"), separate_queues=sep)
 
 
+def test_deferred_logic_call_patterns():
+    """flx_wf_logic is deferred until the next call shows whether the material kernels follow (api.hip).  Call sequences that break the
+    logic -> [genRays ->] materials pattern, ask for something in between or repeat a call must give what the oracle gives for the
+    same sequence, and the fused pass must run exactly when the pattern is complete."""
+    d = common.mixed_material_scene()
+    w, h, n = 64, 48, 4096 + 37                      # not a multiple of the block sizes
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)
+    g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
+    _free_run(g, o, w * h, 3)                        # some mixed steady state
+    p2 = p.copy(); p2["maxBounces"] = 3
+
+    def tail(c):
+        c.wf_extend(); c.wf_shadow()
+
+    patterns = {
+        "plain": (lambda c: (c.wf_logic(False), c.wf_raygen(), c.wf_materials(), tail(c)), 1),
+        "materials first": (lambda c: (c.wf_logic(False), c.wf_materials(), c.wf_raygen(), tail(c)), 1),
+        "no raygen": (lambda c: (c.wf_logic(False), c.wf_materials(), tail(c)), 1),
+        "counters in between": (lambda c: (c.wf_logic(False), np.array(c.get_counters()), c.finish(), c.wf_raygen(), c.wf_materials(), tail(c)), 0),
+        "counters after raygen": (lambda c: (c.wf_logic(False), c.wf_raygen(), c.get_counters(), c.wf_materials(), tail(c)), 0),
+        "params in between": (lambda c: (c.wf_logic(False), c.set_params(p2), c.wf_raygen(), c.wf_materials(), c.set_params(p), tail(c)), 0),
+        "export in between": (lambda c: (c.wf_logic(False), c.state_export(), c.wf_raygen(), c.wf_materials(), tail(c)), 0),
+        "logic without materials": (lambda c: (c.wf_logic(False), c.wf_raygen(), tail(c)), 0),
+        # material counters not known to be zero (set_counters by the sync below, no clear since): the fused scatter could not number the
+        # lists from zero, so the plain kernels must run
+        "counters unknown": (lambda c: (c.wf_logic(False), c.wf_raygen(), c.wf_materials(), tail(c)), 0),
+    }
+    for name, (seq, fused_passes) in patterns.items():
+        common.sync(g, o)
+        if name != "counters unknown":
+            for c in (g, o):
+                c.clear_queues()
+        g.profile_enable(1); g.profile_reset()
+        seq(g); seq(o)
+        _compare(g, o, name)
+        prof = g.profile_get(); g.profile_enable(0)
+        want = fused_passes if TRACE_MODE["fuse"] else 0
+        assert prof["logic_fused"][1] == want, (name, prof)
+        for c in (g, o):
+            c.clear_queues()
+            c.pixel_index_update(w * h, 100)
+
+
 @pytest.mark.parametrize("sep", [0, 1])
 def test_free_running_render_bit_identical(sep):
     """40 benchmark-style iterations without re-synchronising: counters per iteration, final state and image."""
