@@ -23,6 +23,7 @@ void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, con
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 uint32_t fused_queue_mask(int);
+uint32_t logic_aux_stride(uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
@@ -244,9 +245,11 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     }
     if (dalloc(c, c->fixedAllocs, &c->qs.counters, 8)) return fail("hipMalloc(counters)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->qs.counters, 0, 32, c->stream);
-    const uint32_t blocks = (num_tasks + 255) / 256;
-    if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * blocks) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * blocks))
+    const size_t auxStride = logic_aux_stride(num_tasks);          // per list, padded for the scan kernel's uint4 accesses
+    if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * auxStride) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * auxStride))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->blockCounts, 0, (size_t)7 * auxStride * 4, c->stream);      // the pad behind each list's counts stays zero
+    (void)hipMemsetAsync(c->blockOffsets, 0, (size_t)7 * auxStride * 4, c->stream);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     if (dalloc(c, c->fixedAllocs, &c->stats, FLX_NUM_TRACE_STATS)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream);
