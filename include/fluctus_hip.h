@@ -54,7 +54,10 @@ int flx_set_params(flx_ctx *ctx, const void *render_params_240);
 
 /* enqueueWfResetKernel / RaygenKernel / ExtRayKernel / ShadowRayKernel / LogicKernel /
  * MaterialKernels (src/clcontext.cpp:765-848).  Kernels: src/wf_reset.cl, wf_raygen.cl,
- * wf_extrays.cl, wf_shadowrays.cl, wf_logic.cl, wf_mat_*.cl. */
+ * wf_extrays.cl, wf_shadowrays.cl, wf_logic.cl, wf_mat_*.cl.
+ * All of them enqueue and return, as the reference's do.  With option "fuse" (default on, see flx_set_option) flx_wf_logic and a
+ * flx_wf_raygen directly behind it are enqueued by the NEXT call on the context instead -- together with the material kernels as one
+ * pass when that call is flx_wf_materials -- which no other call can tell from immediate launches except by timing. */
 int flx_wf_reset(flx_ctx *ctx);
 int flx_wf_raygen(flx_ctx *ctx);
 int flx_wf_extend(flx_ctx *ctx);
