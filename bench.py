@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--shadow-tree", type=int, default=4, choices=(2, 4))
     ap.add_argument("--overlap", type=int, default=2)
     ap.add_argument("--fuse", type=int, default=1, choices=(0, 1), help="logic + material kernels as one fused pass (default) or the separate kernels")
+    ap.add_argument("--ext-order", type=int, default=-1, choices=(-1, 0, 1), help="fused pass: extension queue lists the continuing paths by path id (1) or in one segment per material queue (0); -1 = what flx_upload_scene chose")
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
@@ -207,6 +208,8 @@ def main():
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene
+        if args.ext_order >= 0:
+            c_.set_option("ext_order", args.ext_order)
         c_.upload_envmap(env)
         c_.set_partition(rank * C + i, world * C)
         c_.set_params(p)
@@ -435,7 +438,7 @@ def main():
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
                                     "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
-                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0,
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},

@@ -19,9 +19,9 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
-void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int);
+void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
-void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
+void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t, int);
 uint32_t fused_queue_mask(int);
 uint32_t logic_aux_stride(uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
@@ -60,6 +60,7 @@ struct flx_ctx {
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
     // settles the deferred calls first, so no call ever observes a state the separate kernels would not have produced.
     int fuse = 1;
+    int extOrder = 1;                           // fused pass: extension queue lists the continuing paths 1 by path id | 0 one segment per material queue (logic.hip)
     int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 3 + glossy | 31 all; chosen at flx_upload_scene
     int pend = 0;                               // 0 nothing deferred | 1 flx_wf_logic | 2 flx_wf_logic, flx_wf_raygen
     int pendFirst = 0;                          // the deferred flx_wf_logic's `first`
@@ -332,6 +333,12 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
             if (t.matId >= 0 && (size_t)t.matId < nmat && mats[t.matId].type == FLX_BXDF_DIFFUSE) areaDiffuse += a;
         }
         c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.5 * areaAll) ? 31 : 1;
+        // ... and the order in which the fused pass lists the continuing paths in the extension queue (logic.hip: k_queue_scatter): one
+        // segment per material queue, as the separate kernels append them, or all of them by path id.  Same-box A/B, Mrays/s segments ->
+        // path id: conference 4318 -> 4446 (+3 %: three BSDF types of similar weight, the segments cut the id order into thirds),
+        // kitchen 4278 -> 4230, courtyard 1678 -> 1652 (one dominant type: its segment IS the id order, and the small segments of the
+        // other types are rays leaving the same few objects).  Option "ext_order" overrides.
+        c->extOrder = c->fuseSet == 31 ? 1 : 0;
     }
 
     // 1. leaf triangle records, in index-list order (a leaf is a contiguous run of the list)
@@ -545,7 +552,7 @@ static int runRaygen(flx_ctx *c)
 static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
     flushExt(c);                                       // logic's scan overwrites the source-queue counters
-    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst); }
+    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, c->extOrder); }
     LAUNCHED(c);
     c->matQueuesEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -657,7 +664,7 @@ int flx_wf_materials(flx_ctx *c)
         if (runLogic(c, c->pendFirst, c->fuseSet, pd == 2)) return 1;
         if (pd == 2 && runRaygen(c)) return 1;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
-        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet)); }
+        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), c->extOrder); }
         LAUNCHED(c);
         c->qs.extPend |= materialBits(c);
         if (c->eagerBump) flushExt(c);
@@ -1063,6 +1070,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (settle(c)) return 1;
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
+    if (name && strcmp(name, "ext_order") == 0 && (value == 0 || value == 1)) { c->extOrder = value; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->shadowTree = value; return 0; }
@@ -1082,7 +1090,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;
     return 1;

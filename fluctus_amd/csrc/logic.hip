@@ -310,10 +310,14 @@ __global__ __launch_bounds__(1024) void k_queue_scan(LogicAux aux, uint32_t *cou
 }
 
 // stable scatter: rank within block by wave ballots, block base from the scan.
-// FUSED: the material lists are also appended to the extension queue, at the slots the material kernels compute
-// (material.hip: extension base [+ the raygen queue when genRays was enqueued before the material kernels] + the material
-// queues before this one + own index).  Needs material queues that were empty before this `logic` (the host checks).
-__global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicAux aux, uint32_t numTasks, int fuse, uint32_t raygenFirst)
+// fuse != 0: the scatter also writes the extension-queue entries of EVERY continuing path -- inlined BSDF type or not; the material
+// kernel that serves the other types afterwards does not append -- as one list in path-id order behind (or in front of) the regenerated
+// paths, where the separate material kernels append one segment per material queue.  The extension queue is a set (the reference fills
+// it with atomic_inc in whatever order the work-items arrive, src/utils.cl:328-358); its order only decides which lane traces which ray,
+// and neighbouring path ids are neighbouring pixels' paths: on the same 4 M rays k_extend4 takes 0.730 ms in path-id order against
+// 0.800 ms in per-material segments on the conference scene (three BSDF types of similar weight), 0.912 against 0.933 ms on the kitchen,
+// 1.30 / 1.10 ms shuffled (scripts/exp_octant.py).  Needs material queues that were empty before this `logic` (the host checks).
+__global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicAux aux, uint32_t numTasks, int fuse, uint32_t raygenFirst, uint32_t byPathId)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
     const uint32_t member = gid < numTasks ? aux.member[gid] : 0u;
@@ -337,12 +341,21 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
             for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w];
             r += mbcnt(bal[l]);
             outq[l][r] = gid;
-            if (fuse != 0 && l >= 2 && fuse_inlines_list(fuse, (uint32_t)(l - 1))) {
+            if (fuse != 0 && !byPathId && l >= 2 && fuse_inlines_list(fuse, (uint32_t)(l - 1))) {
+                // option ext_order 0: the separate kernels' order -- one segment per material queue; the types that are not inlined
+                // are appended by their material kernel
                 uint32_t base = ext_len(qs) + (raygenFirst ? qs.counters[FLX_Q_RAYGEN] : 0u);
                 for (int q = FLX_Q_DIFFUSE; q < FLX_Q_DIFFUSE + (l - 2); q++) base += qs.counters[q];
                 qs.q[FLX_Q_EXTENSION][base + r] = gid;
             }
         }
+    }
+    if (fuse != 0 && byPathId && ml != 0u) {
+        // the continuing paths of ALL material lists, in path-id order (see the comment above the kernel)
+        uint32_t r = s_off[2] + s_off[3] + s_off[4] + s_off[5] + s_off[6];
+        for (uint32_t w = 0; w < wave; w++) r += s_cnt[2][w] + s_cnt[3][w] + s_cnt[4][w] + s_cnt[5][w] + s_cnt[6][w];
+        r += mbcnt(bal[2] | bal[3] | bal[4] | bal[5] | bal[6]);
+        qs.q[FLX_Q_EXTENSION][ext_len(qs) + (raygenFirst ? qs.counters[FLX_Q_RAYGEN] : 0u) + r] = gid;
     }
 }
 
@@ -364,7 +377,7 @@ uint32_t fused_queue_mask(int fuse)
 
 // fuse: 0 = the plain logic kernel | USE_DIFFUSE | USE_ALL  (diffuse + glossy was measured too: never the best of the three)
 void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
-                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst)
+                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId)
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
@@ -376,7 +389,7 @@ void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene 
     default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
     }
     hipLaunchKernelGGL(k_queue_scan, dim3(NUM_LISTS), dim3(1024), 0, s, aux, qs.counters);
-    hipLaunchKernelGGL(k_queue_scatter, g, b, 0, s, qs, aux, st.numTasks, fuse, (uint32_t)raygenFirst);
+    hipLaunchKernelGGL(k_queue_scatter, g, b, 0, s, qs, aux, st.numTasks, fuse, (uint32_t)raygenFirst, (uint32_t)extByPathId);
 }
 
 } // namespace flxd

@@ -19,6 +19,9 @@ namespace flxd {
 #define MAT_BLOCK 64            // one wave per block: interleaves best with the one-wave blocks of the concurrent shadow traversal (+1 %)
 #endif
 
+// earlierMask: the material queues appended to the extension queue before this one; FLX_NO_APPEND: the extension-queue entries of
+// this iteration's continuing paths exist already (written by the fused logic pass's scatter, logic.hip)
+#define FLX_NO_APPEND 0x80000000u
 template <int USE>
 __device__ __forceinline__ void material_body(const State &st, const Queues &qs, const Scene &sc, int queueId, uint32_t idx, uint32_t earlierMask)
 {
@@ -45,7 +48,7 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
         wr4(st.at(S_ORIG, gid), mk4(o.orig, o.pdfW));
         wr4(st.at(S_DIR, gid), mk4u(o.newDir, __float_as_uint(d4.w) & ~FLX_FRESH));   // pathLen; "no material kernel since regeneration" ends here
     }
-    if (active) {
+    if (active && !(earlierMask & FLX_NO_APPEND)) {
         // slot = extBase + lengths of the material queues appended before this one + own index (flx_device.h)
         uint32_t base = ext_len(qs);
         for (int q = FLX_Q_DIFFUSE; q < FLX_NUM_QUEUES; q++) if (earlierMask & (1u << q)) base += qs.counters[q];
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(MAT_BLOCK) void k_material(State st, Queues qs, Sce
 // doneMask: queues the fused logic pass has already served (logic.hip); they only count as "appended earlier".
 __global__ __launch_bounds__(MAT_BLOCK) void k_material_rest(State st, Queues qs, Scene sc, uint32_t doneMask)
 {
+    const uint32_t noAppend = doneMask & FLX_NO_APPEND;
     uint32_t nbq[4], total = 0;
     for (int q = FLX_Q_GLOSSY; q <= FLX_Q_DELTA; q++) {
         nbq[q - FLX_Q_GLOSSY] = (doneMask & (1u << q)) ? 0u : (qs.counters[q] + MAT_BLOCK - 1) / MAT_BLOCK;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(MAT_BLOCK) void k_material_rest(State st, Queues qs
     }
     for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
         uint32_t b = vb;
-        uint32_t earlier = 1u << FLX_Q_DIFFUSE;
+        uint32_t earlier = (1u << FLX_Q_DIFFUSE) | noAppend;
         for (int q = FLX_Q_GLOSSY; q <= FLX_Q_DELTA; q++) {
             const uint32_t nb = nbq[q - FLX_Q_GLOSSY];
             if (b < nb) { material_body<USE_GLOSSY | USE_GGX_REFL | USE_GGX_REFR | USE_DELTA>(st, qs, sc, q, b * MAT_BLOCK + threadIdx.x, earlier); break; }
@@ -121,16 +125,18 @@ void launch_materials(hipStream_t s, const State &st, const Queues &qs, const Sc
     }
 }
 
-// what is left of flx_wf_materials after the fused logic pass (separate queues): the queues in doneMask are served already
-void launch_materials_after_fused(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, uint32_t doneMask)
+// what is left of flx_wf_materials after the fused logic pass (separate queues): the queues in doneMask are served already, and
+// the extension-queue entries of every continuing path are written (so nothing appends here)
+void launch_materials_after_fused(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, uint32_t doneMask, int extWritten)
 {
+    const uint32_t FLX_NO_APPEND_ = extWritten ? FLX_NO_APPEND : 0u;
     const uint32_t all = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
     if ((doneMask & all) == all) return;
-    if (!(doneMask & (1u << FLX_Q_DIFFUSE))) launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, 0u);
+    if (!(doneMask & (1u << FLX_Q_DIFFUSE))) launch_one(s, st, qs, sc, FLX_Q_DIFFUSE, USE_DIFFUSE, FLX_NO_APPEND_);
     if ((doneMask & (all & ~(1u << FLX_Q_DIFFUSE))) != (all & ~(1u << FLX_Q_DIFFUSE))) {
         uint32_t blocks = (st.numTasks + MAT_BLOCK - 1) / MAT_BLOCK + 4;
         if (blocks > MAT_GRID) blocks = MAT_GRID;
-        hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, doneMask);
+        hipLaunchKernelGGL(k_material_rest, dim3(blocks), dim3(MAT_BLOCK), 0, s, st, qs, sc, doneMask | FLX_NO_APPEND_);
     }
 }
 

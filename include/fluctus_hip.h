@@ -196,12 +196,15 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     flx_wf_materials (a flx_wf_raygen between the two is deferred along and launched right after), logic and the
  *                     material step of the most common BSDF types run as ONE pass over the path state (logic.hip: k_logic<FUSED>),
  *                     the other types through their queues as usual; when it is anything else, the plain kernel runs first.  No call
- *                     can observe a state, queue or counter the separate kernels would not have produced (the extension queue keeps
- *                     their order); an error raised by a deferred launch is reported by the call that launched it.  Needs the
+ *                     can observe a state, queue or counter the separate kernels would not have produced (but see ext_order for
+ *                     the ORDER of the extension queue); an error raised by a deferred launch is reported by the call that launched it.  Needs the
  *                     material queues empty (flx_clear_queues / flx_end_iteration_async since the last logic) and wfSeparateQueues
  *                     (or a build that inlines every type) -- otherwise, and with 0, every call launches its own kernels at once
  *   fuse_set          BSDF types the fused pass inlines: 1 diffuse only | 31 all six.  flx_upload_scene picks it from the scene
  *                     (diffuse surfaces >= half of the triangle area: 1, else 31); set it after the upload to override
+ *   ext_order         how the fused pass lists the continuing paths in the extension queue: 0 one segment per material queue, in the
+ *                     separate kernels' order | 1 all of them by path id (the same SET of paths either way; the reference's order is
+ *                     whatever its atomic_inc produces).  flx_upload_scene picks it with fuse_set (1 with 31); set it afterwards to override
  *   node_layout       1 (default) sibling-pair record numbering of the binary tree | 0 DFS numbering; takes effect at the next flx_upload_scene
  *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
  *   xcd_remap, eager_bump: A/B knobs of the binary kernels */

@@ -40,6 +40,8 @@ orders = {
     "origin cell 16^3 (stable)": np.argsort(morton, kind="stable"),
     "octant + origin cell": np.argsort(octant.astype(np.uint64) << 16 | morton, kind="stable"),
     "origin cell + octant": np.argsort(morton.astype(np.uint64) << 3 | octant, kind="stable"),
+    "by path id (all)": np.argsort(q, kind="stable"),
+    "regenerated first, then the rest by path id": np.concatenate([np.arange(int(cnt[0])), int(cnt[0]) + np.argsort(q[int(cnt[0]):], kind="stable")]),
     "shuffled": rng.permutation(m),
 }
 c.set_option("overlap", 0)

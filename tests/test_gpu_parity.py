@@ -51,10 +51,11 @@ def _ctxs(d, p, n, env=None):
         driver.reset_renderer(c)
     if TRACE_MODE["fuse_set"]:
         g.set_option("fuse_set", TRACE_MODE["fuse_set"])          # after the upload, which picks one for the scene
+        g.set_option("ext_order", 1 if TRACE_MODE["fuse_set"] == 31 else 0)
     return g, o
 
 
-def _compare(g, o, what, check_queues=True):
+def _compare(g, o, what, check_queues=True, ext_set=False):
     cg, co = g.get_counters(), o.get_counters()
     g.finish()
     assert (cg == co).all(), f"{what}: counters {cg} vs {co}"
@@ -62,6 +63,20 @@ def _compare(g, o, what, check_queues=True):
         for q in range(8):
             n = int(co[q])
             qa, qb = g.queue_read(q)[:n], o.queue_read(q)[:n]
+            if q == Q.EXTENSION and ext_set:
+                # the fused pass lists the continuing paths in path-id order where the separate material kernels append one segment
+                # per material queue: the same SET (the reference's own order is whatever its atomic_inc produces), the regenerated
+                # paths' block where the call order puts it
+                assert np.array_equal(np.sort(qa), np.sort(qb)), f"{what}: extension queue holds different paths"
+                r = int(co[Q.RAYGEN])
+                regen = o.queue_read(Q.RAYGEN)[:r]
+                if r and n > r and np.array_equal(qb[:r], regen):              # genRays was enqueued before the material kernels
+                    assert np.array_equal(qa[:r], regen), f"{what}: regenerated block of the extension queue"
+                    assert (np.diff(qa[r:].astype(np.int64)) > 0).all(), f"{what}: continuing paths not in path-id order"
+                elif r and n > r and np.array_equal(qb[n - r:], regen):        # ... or after them
+                    assert np.array_equal(qa[n - r:], regen), f"{what}: regenerated block of the extension queue"
+                    assert (np.diff(qa[:n - r].astype(np.int64)) > 0).all(), f"{what}: continuing paths not in path-id order"
+                continue
             # all queues, the extension queue included, are in canonical order (stable compaction + computed slots)
             assert np.array_equal(qa, qb), f"{what}: queue {q} differs"
     fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
@@ -98,11 +113,12 @@ def _lockstep_iterations(g, o, npix, iters, order=("logic", "raygen", "materials
             c.clear_queues()                        # the state sync above rewrote the counters: the queues are empty, say so
             for name in order:
                 fns[name](c)
-        _compare(g, o, f"it{it} {'+'.join(order)}")
+        fused_now = bool(TRACE_MODE["fuse"] and (separate_queues or g.get_option("fused_queue_mask") == 0xF8)) and g.get_option("ext_order") == 1
+        _compare(g, o, f"it{it} {'+'.join(order)}", ext_set=fused_now)
         cnt = o.get_counters().copy()
         for c in (g, o):
             c.wf_extend(); c.wf_shadow()
-        _compare(g, o, f"it{it} extend+shadow")
+        _compare(g, o, f"it{it} extend+shadow", ext_set=fused_now)
         for c in (g, o):
             c.clear_queues()
             c.pixel_index_update(npix, int(cnt[0]))
@@ -184,9 +200,9 @@ def test_deferred_logic_call_patterns():
                 c.clear_queues()
         g.profile_enable(1); g.profile_reset()
         seq(g); seq(o)
-        _compare(g, o, name)
-        prof = g.profile_get(); g.profile_enable(0)
         want = fused_passes if TRACE_MODE["fuse"] else 0
+        _compare(g, o, name, ext_set=bool(want) and g.get_option("ext_order") == 1)
+        prof = g.profile_get(); g.profile_enable(0)
         assert prof["logic_fused"][1] == want, (name, prof)
         for c in (g, o):
             c.clear_queues()
