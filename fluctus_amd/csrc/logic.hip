@@ -26,7 +26,9 @@
 
 namespace flxd {
 
+#ifndef LOGIC_BLOCK
 #define LOGIC_BLOCK 256
+#endif
 // FUSE = the BSDF types the fused pass evaluates inline (0: none, the plain logic kernel); paths of the other types take the usual
 // route through their material queue and the `k_material_rest` kernel (material.hip).  Inlining costs registers for every type compiled
 // in (logic alone 68 VGPRs; + diffuse 94; + glossy 104; all six 106 and 4 waves/SIMD), so the host picks the set per scene from the
