@@ -174,7 +174,8 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask)
 // queues appended before this one in the same call) + index in the own source queue.  extBase is the
 // extension counter as left by the previous call; a 1-thread kernel adds the appended total
 // afterwards (stream order).  The extension queue thus is the concatenation
-// [raygen | diffuse | glossy | ggxRefl | ggxRefr | delta] in source order: deterministic.
+// [raygen | diffuse | glossy | ggxRefl | ggxRefr | delta] in source order: deterministic.  (The fused logic + material pass writes the
+// material part itself, in these segments or as one list by path id: logic.hip, k_queue_scatter.)
 // The bump itself is LAZY: the host remembers which source queues were appended (Queues::extPend) and every kernel
 // that needs the extension-queue length adds those lengths on the fly (ext_len); the 1-thread bump kernel
 // (k_bump_extension, misc.hip) only runs when someone outside these kernels looks at the counter
