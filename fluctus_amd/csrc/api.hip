@@ -587,7 +587,10 @@ int flx_wf_extend(flx_ctx *c)
 {
     READY(c);
     KEEP_CHAIN(c);
-    if (c->overlap) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));      // "everything enqueued before the extension kernel"
+    // "everything enqueued before the extension kernel": what a concurrent shadow kernel waits for -- unless it may start right after
+    // `logic` (overlap 2 with the chain intact: it then waits for evPostLogic instead, and this marker would only put one more barrier
+    // packet in front of the extension kernel)
+    if (c->overlap && !(c->overlap == 2 && c->logicChain)) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
