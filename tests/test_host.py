@@ -283,6 +283,51 @@ def test_envmap_alias_tables_are_a_valid_alias_method():
     assert e.pdf.reshape(h, w)[3, 5] == e.pdf.max()
 
 
+def _env_tables_by_the_reference_rules(img):
+    """EnvironmentMap::computeProbabilities restated in numpy / plain Python (src/envmap.cpp:31-114): luminance x sin(theta) per texel in
+    fp32 (libm sinf, as std::sin(float) resolves to), the integral as a sequential fp32 sum of scalar / n, pdf = scalar / I (1 / n when I is
+    0), then Vose's alias method with two LIFO stacks split at p < 1, the large entry re-filed with (g + l) - 1."""
+    import ctypes
+    sinf = ctypes.CDLL("libm.so.6").sinf
+    sinf.restype, sinf.argtypes = ctypes.c_float, [ctypes.c_float]
+    f32 = np.float32
+    h, w, _ = img.shape
+    n = w * h
+    pi = f32(3.14159265358979323846)
+    sin_th = np.array([sinf(f32(pi * f32(v + 0.5)) / f32(h)) for v in range(h)], f32)
+    r, g, b = img[..., 0].astype(f32), img[..., 1].astype(f32), img[..., 2].astype(f32)
+    lum = (f32(0.212671) * r + f32(0.715160) * g) + f32(0.072169) * b
+    scalars = (lum * sin_th[:, None]).astype(f32).reshape(-1)
+    integral = np.cumsum(scalars / f32(n), dtype=f32)[-1]                    # I += scalars[i] / (w * h), in index order
+    pdf = np.full(n, f32(1.0) / f32(n), f32) if integral == 0 else (scalars / integral).astype(f32)
+    prob, alias = np.ones(n, f32), np.arange(n, dtype=np.int32)
+    small = [(p_, i) for i, p_ in enumerate(pdf) if p_ < 1.0]
+    large = [(p_, i) for i, p_ in enumerate(pdf) if not (p_ < 1.0)]
+    while small and large:
+        (pl, il), (pg, ig) = small.pop(), large.pop()
+        prob[il], alias[il] = pl, ig
+        pg2 = f32(f32(pg + pl) - f32(1.0))
+        (small if pg2 < 1.0 else large).append((pg2, ig))
+    return pdf, prob, alias
+
+
+@pytest.mark.parametrize("w,h,seed", [(48, 24, 0), (64, 32, 1), (7, 5, 2)])
+def test_envmap_tables_match_an_independent_restatement(w, h, seed):
+    """host/envmap.cpp's pdf / probability / alias tables, bit for bit, against a second restatement of the reference's algorithm written
+    in numpy (the reference's envmap.cpp cannot be built here: utils.h -> glad).  Entries whose probability ends at 1 never consult
+    their alias; the reference leaves it uninitialised there, so it is compared only where prob < 1."""
+    rng = np.random.RandomState(seed)
+    img = (rng.rand(h, w, 3).astype(np.float32) ** 4) * np.float32(3.0)
+    img[h // 3, w // 5] = 500.0
+    img[h - 1, :] = 0.0                                                        # a black row
+    e = host.envmap_from_rgb(w, h, img)
+    pdf, prob, alias = _env_tables_by_the_reference_rules(img)
+    assert np.array_equal(e.pdf.view(np.uint32), pdf.view(np.uint32))
+    assert np.array_equal(e.prob.view(np.uint32), prob.view(np.uint32))
+    used = prob < 1.0
+    assert np.array_equal(e.alias[used], alias[used])
+
+
 def test_envmap_all_black_falls_back_to_uniform():
     e = host.envmap_from_rgb(8, 4, np.zeros((4, 8, 3), np.float32))
     assert np.allclose(e.pdf, 1.0 / 32.0) and (e.prob <= 1.0).all()   # reference: src/envmap.cpp:62-63
