@@ -60,8 +60,8 @@ struct flx_ctx {
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
     // settles the deferred calls first, so no call ever observes a state the separate kernels would not have produced.
     int fuse = 1;
-    int extOrder = 1;                           // fused pass: extension queue lists the continuing paths 1 by path id | 0 one segment per material queue (logic.hip)
-    int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 3 + glossy | 31 all; chosen at flx_upload_scene
+    int extOrder = 0;                           // fused pass: extension queue lists the continuing paths 1 by path id | 0 one segment per material queue; chosen at flx_upload_scene
+    int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 31 all six; chosen at flx_upload_scene
     int pend = 0;                               // 0 nothing deferred | 1 flx_wf_logic | 2 flx_wf_logic, flx_wf_raygen
     int pendFirst = 0;                          // the deferred flx_wf_logic's `first`
     bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
