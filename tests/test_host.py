@@ -144,6 +144,44 @@ def test_wide_tree_degenerate_inputs():
         host.wide_tree_check(d)
 
 
+def _soup(n, seed, long_share=0.3):
+    """n random triangles in general position (no axis-aligned or coplanar sets: the reference's binning divides by the node extent),
+    a share of them long and thin so that spatial splits pay."""
+    rng = np.random.RandomState(seed)
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    size = np.where(rng.rand(n, 1, 1) < long_share, rng.uniform(0.8, 2.0, (n, 1, 1)), rng.uniform(0.03, 0.25, (n, 1, 1)))
+    v = (c + rng.normal(size=(n, 3, 3)) * size * np.array([1.0, 0.15, 0.4])).astype(np.float32)
+    d = host.SceneData()
+    t = np.zeros(n, wire.TRIANGLE)
+    for k, name in enumerate(("v0", "v1", "v2")):
+        for a, ax in enumerate("xyz"):
+            t[name]["p"][ax] = v[:, k, a]
+        t[name]["n"]["y"] = 1.0
+    d.tris = t
+    return d, v
+
+
+@pytest.mark.parametrize("n,seed", [(60, 1), (140, 2), (220, 3)])
+def test_sbvh_matches_an_independent_restatement(n, seed):
+    """host/bvh.cpp's Mode::SBVH against tests/sbvh_restatement.py -- the reference's builder (src/sbvh.cpp) restated a second time,
+    in Python over fp32 scalars -- node for node and index for index (boxes bit for bit), on triangle soups where spatial splits,
+    unsplitting and duplication all occur.  The reference's own sbvh.cpp cannot be built here (progressview.hpp -> nanogui)."""
+    from sbvh_restatement import SBVH
+    d, verts = _soup(n, seed)
+    host.build_bvh(d, "sbvh", threads=1)
+    ref = SBVH(verts)
+    assert ref.spatial > 0 and ref.duplicates > 0, "the scene is meant to exercise spatial splits"
+    assert d.bvh_metrics["duplicates"] == ref.duplicates and d.bvh_metrics["splits"] == ref.splits and d.bvh_metrics["depth"] == ref.depth
+    assert np.array_equal(d.indices, np.array(ref.indices, np.uint32))
+    assert d.nodes.size == len(ref.nodes)
+    for i, (box, parent, link, nprims) in enumerate(ref.nodes):
+        nd = d.nodes[i]
+        got = np.array([nd["bmin"]["x"], nd["bmin"]["y"], nd["bmin"]["z"], nd["bmax"]["x"], nd["bmax"]["y"], nd["bmax"]["z"]], np.float32)
+        want = np.array(box.mn + box.mx, np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"node {i}: box"
+        assert int(nd["parent"]) == parent and int(nd["iStartOrRight"]) == link and int(nd["nPrims"]) == nprims, f"node {i}"
+
+
 def test_sbvh_creates_duplicates_only_with_spatial_splits():
     d = host.generate_scene("conference", 20000, 43)
     host.build_bvh(d, "sbvh")
