@@ -231,8 +231,18 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                 // direction" is this iteration's sample when NEE stored one, else whatever the record holds (the material kernels
                 // evaluate toward it regardless, src/wf_mat_diffuse.cl:34-37; logic consumes the result only behind an unblocked ray)
                 const f3 L = haveL ? Lnee : ld3(rd4(st.at(S_SHD, gid)));
-                SurfHit h; h.P = hitP; h.N = hitN; h.uv = hitUV;
-                const MatStep o = material_step<FUSE>(sc, h, mat, backface, rayDir, L, T, &seed);
+                MatStep o;
+                if (FUSE == USE_ALL) {
+                    // the all-types kernel is register-bound (106 VGPRs, 4 waves/SIMD): re-reading the hit point, uv, material and ray
+                    // direction here (L1/L2-hot, this thread loaded them above) instead of keeping them live across the NEE code brings
+                    // it to 87 VGPRs and 5 waves (-3 % kernel time); the diffuse-only kernel stays at 5 waves either way
+                    const float4 hp2 = rd4(st.at(S_HITP, gid)), huv2 = rd4(st.at(S_HITUV, gid)), d42 = rd4(st.at(S_DIR, gid));
+                    SurfHit h; h.P = ld3(hp2); h.N = hitN; h.uv = mk2(huv2.x, huv2.y);
+                    o = material_step<FUSE>(sc, h, sc.materials[__float_as_int(huv2.w)], backface, ld3(d42), L, T, &seed);
+                } else {
+                    SurfHit h; h.P = hitP; h.N = hitN; h.uv = hitUV;
+                    o = material_step<FUSE>(sc, h, mat, backface, rayDir, L, T, &seed);
+                }
                 wr4(st.at(S_LBSDF, gid), mk4(o.bsdfNEE, o.bsdfPdfW));
                 wr4(st.at(S_LT, gid), mk4u(T, o.singular));
                 wr4(st.at(S_THR, gid), mk4u(o.newT, seed));
