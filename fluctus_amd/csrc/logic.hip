@@ -31,7 +31,7 @@ namespace flxd {
 #endif
 // FUSE = the BSDF types the fused pass evaluates inline (0: none, the plain logic kernel); paths of the other types take the usual
 // route through their material queue and the `k_material_rest` kernel (material.hip).  Inlining costs registers for every type compiled
-// in (logic alone 68 VGPRs; + diffuse 94; + glossy 104; all six 106 and 4 waves/SIMD), so the host picks the set per scene from the
+// in (logic alone 68 VGPRs; + diffuse 94; + glossy 104; all six 106 = 4 waves/SIMD, 87 with the re-reads below), so the host picks the set per scene from the
 // BSDF types its triangles use (api.hip) -- the reference specialises its kernels per scene the same way (-DBXDF_USE_*, src/clcontext.cpp).
 __host__ __device__ constexpr bool fuse_inlines_list(int fuse, uint32_t ml)     // ml = material_list(): 1 diffuse .. 5 delta
 {
