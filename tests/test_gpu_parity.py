@@ -378,6 +378,32 @@ def test_full_size_properties_and_determinism(workload):
     assert common.fb_close(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("workload", ["kitchen", "conference"])
+def test_full_size_free_run_vs_oracle(workload):
+    """The bench scenes themselves (kitchen-proc 0.5 M triangles 1080p env-map MIS; conference-proc area light, GGX / glossy / diffuse) with
+    1 M paths in flight, 10 free-running iterations on the product's default path (fused logic pass, 4-wide any-hit, two streams) and
+    the bit-exact closest hit, against the oracle: counters after every iteration, the final path state bit for bit, the framebuffer."""
+    if TRACE_MODE != {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_set": 0}:
+        pytest.skip("default configuration only (the variants run on the small scenes)")
+    from fluctus_amd.device import HipContext
+    from oracle.binding import OracleContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    g, o = HipContext(n), OracleContext(n, threads=16)
+    g.set_option("extend_tree", 2)
+    for c in (g, o):
+        c.upload_scene(d); c.upload_envmap(env); c.set_params(p); driver.reset_renderer(c)
+    for it in range(10):
+        cg = driver.benchmark_iteration(g, npix)
+        co = driver.benchmark_iteration(o, npix)
+        assert (cg == co).all(), f"iteration {it}: counters {cg} vs {co}"
+    fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+    assert not fails, "; ".join(fails[:5])
+    assert common.fb_close(g.read_pixels(0), o.read_pixels(0))
+    g.close()
+
+
 def test_c_abi_error_paths():
     """Errors come back as return codes + flx_last_error, never as crashes or silent fallbacks."""
     import ctypes as C
