@@ -378,9 +378,10 @@ def test_full_size_properties_and_determinism(workload):
     assert common.fb_close(outs[0][2], outs[1][2])
 
 
-@pytest.mark.parametrize("workload", ["kitchen", "conference"])
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
 def test_full_size_free_run_vs_oracle(workload):
-    """The bench scenes themselves (kitchen-proc 0.5 M triangles 1080p env-map MIS; conference-proc area light, GGX / glossy / diffuse) with
+    """The bench scenes themselves (kitchen-proc 0.5 M triangles 1080p env-map MIS; conference-proc area light, GGX / glossy / diffuse;
+    courtyard-proc 8.9 M triangles 1440p 12 bounces, all six BSDFs) with
     1 M paths in flight, 10 free-running iterations on the product's default path (fused logic pass, 4-wide any-hit, two streams) and
     the bit-exact closest hit, against the oracle: counters after every iteration, the final path state bit for bit, the framebuffer."""
     if TRACE_MODE != {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_set": 0}:
