@@ -15,7 +15,7 @@ struct HipContext::Api {
     FN(flx_clear_queues) FN(flx_get_counters_async) FN(flx_finish) FN(flx_pixel_index_update) FN(flx_pixel_index_reset)
     FN(flx_num_tasks) FN(flx_postprocess) FN(flx_read_pixels) FN(flx_set_partition) FN(flx_local_pixels)
     FN(flx_mk_reset) FN(flx_mk_raygen) FN(flx_mk_next_vertex) FN(flx_mk_sample_bsdf) FN(flx_mk_splat) FN(flx_mk_splat_preview)
-    FN(flx_mk_stats_async) FN(flx_mk_stats_reset) FN(flx_set_option) FN(flx_group_init_local) FN(flx_gather_local)
+    FN(flx_mk_stats_async) FN(flx_mk_stats_reset) FN(flx_set_option) FN(flx_get_option) FN(flx_group_init_local) FN(flx_gather_local)
 #undef FN
 };
 
@@ -42,7 +42,7 @@ HipContext::HipContext(int device, uint32_t numTasks, const std::string &libPath
     BIND(flx_clear_queues) BIND(flx_get_counters_async) BIND(flx_finish) BIND(flx_pixel_index_update) BIND(flx_pixel_index_reset)
     BIND(flx_num_tasks) BIND(flx_postprocess) BIND(flx_read_pixels) BIND(flx_set_partition) BIND(flx_local_pixels)
     BIND(flx_mk_reset) BIND(flx_mk_raygen) BIND(flx_mk_next_vertex) BIND(flx_mk_sample_bsdf) BIND(flx_mk_splat) BIND(flx_mk_splat_preview)
-    BIND(flx_mk_stats_async) BIND(flx_mk_stats_reset) BIND(flx_set_option) BIND(flx_group_init_local) BIND(flx_gather_local)
+    BIND(flx_mk_stats_async) BIND(flx_mk_stats_reset) BIND(flx_set_option) BIND(flx_get_option) BIND(flx_group_init_local) BIND(flx_gather_local)
 #undef BIND
     if (api->flx_create(device, numTasks, &ctx) != 0)
         throw std::runtime_error(std::string("HipContext: ") + api->flx_last_error(nullptr));
@@ -114,6 +114,7 @@ void HipContext::gatherLocal(const std::vector<HipContext *> &ranks, uint32_t ro
     ranks[root]->check(ranks[root]->api->flx_gather_local(h.data(), (uint32_t)h.size(), root, rgba.data()), "gatherLocal");
 }
 void HipContext::setOption(const std::string &name, int value) { check(api->flx_set_option(ctx, name.c_str(), value), "setOption"); }
+int HipContext::getOption(const std::string &name) { int v = 0; check(api->flx_get_option(ctx, name.c_str(), &v), "getOption"); return v; }
 void HipContext::recompileKernels(bool useDenoiser) { check(api->flx_set_option(ctx, "denoiser", useDenoiser ? 1 : 0), "recompileKernels"); }
 void HipContext::enqueueClearWfQueues() { check(api->flx_clear_queues(ctx), "clear queues"); }
 void HipContext::enqueueGetCounters(QueueCounters *cnt) { check(api->flx_get_counters_async(ctx, cnt), "get counters"); }

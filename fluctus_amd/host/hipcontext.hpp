@@ -47,6 +47,7 @@ public:
     // kernel selection the reference makes through Settings + recompile (src/settings.cpp): "extend_tree" / "shadow_tree" 2 | 4, ...
     // (include/fluctus_hip.h, flx_set_option)
     void setOption(const std::string &name, int value);
+    int getOption(const std::string &name);                    // flx_get_option: current value, e.g. what the upload picked for "fuse_set"
     void enqueueClearWfQueues();                                  // src/clcontext.cpp:877-883
     void enqueueGetCounters(QueueCounters *cnt);                  // async; valid after finishQueue()
     void enqueuePostprocessKernel(const RenderParams &params);
