@@ -124,8 +124,12 @@ __device__ __forceinline__ f3 camera_space_normal(const flx_render_params &p, f3
 
 // Path-state accessors.  Every kernel streams the state exactly once per launch, while the BVH is re-read constantly;
 // FLX_NT marks state loads (bit 0) / stores (bit 1) non-temporal so they do not evict the tree from L2 / Infinity Cache.
+// Round 1 measured nothing from it; on the round-2 kernels (4 M paths = 0.8 GB of state per iteration against a 256 MB Infinity Cache)
+// stores alone give +2.4 % Mrays/s on the kitchen, loads + stores +4 % (k_extend4 0.857 -> 0.833 ms, the fused logic pass 0.42 -> 0.40),
+// +1 % on conference and courtyard.  The kernels that read what another kernel has JUST written through a queue (genRays' seed, the
+// material kernels' records) lose with non-temporal loads and use rd4t.
 #ifndef FLX_NT
-#define FLX_NT 0
+#define FLX_NT 3
 #endif
 typedef float flx_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 rd4(const float4 *p)
@@ -137,6 +141,7 @@ __device__ __forceinline__ float4 rd4(const float4 *p)
     return *p;
 #endif
 }
+__device__ __forceinline__ float4 rd4t(const float4 *p) { return *p; }          // temporal: the line was written moments ago and is wanted from L2
 __device__ __forceinline__ void wr4(float4 *p, float4 v)
 {
 #if FLX_NT & 2

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                     // the all-types kernel is register-bound (106 VGPRs, 4 waves/SIMD): re-reading the hit point, uv, material and ray
                     // direction here (L1/L2-hot, this thread loaded them above) instead of keeping them live across the NEE code brings
                     // it to 87 VGPRs and 5 waves (-3 % kernel time); the diffuse-only kernel stays at 5 waves either way
-                    const float4 hp2 = rd4(st.at(S_HITP, gid)), huv2 = rd4(st.at(S_HITUV, gid)), d42 = rd4(st.at(S_DIR, gid));
+                    const float4 hp2 = rd4t(st.at(S_HITP, gid)), huv2 = rd4t(st.at(S_HITUV, gid)), d42 = rd4t(st.at(S_DIR, gid));
                     SurfHit h; h.P = ld3(hp2); h.N = hitN; h.uv = mk2(huv2.x, huv2.y);
                     o = material_step<FUSE>(sc, h, sc.materials[__float_as_int(huv2.w)], backface, ld3(d42), L, T, &seed);
                 } else {

@@ -30,12 +30,12 @@ __device__ __forceinline__ void material_body(const State &st, const Queues &qs,
     uint32_t gid = 0;
     if (active) {
         gid = qs.q[queueId][idx];
-        const float4 thr = rd4(st.at(S_THR, gid));
-        const float4 hp = rd4(st.at(S_HITP, gid));
-        const float4 hn = rd4(st.at(S_HITN, gid));
-        const float4 huv = rd4(st.at(S_HITUV, gid));
-        const float4 d4 = rd4(st.at(S_DIR, gid));
-        const float4 sd = rd4(st.at(S_SHD, gid));
+        const float4 thr = rd4t(st.at(S_THR, gid));                 // (temporal loads: `logic` has just touched these lines)
+        const float4 hp = rd4t(st.at(S_HITP, gid));
+        const float4 hn = rd4t(st.at(S_HITN, gid));
+        const float4 huv = rd4t(st.at(S_HITUV, gid));
+        const float4 d4 = rd4t(st.at(S_DIR, gid));
+        const float4 sd = rd4t(st.at(S_SHD, gid));
         uint32_t seed = __float_as_uint(thr.w);
         SurfHit h; h.P = ld3(hp); h.N = ld3(hn); h.uv = mk2(huv.x, huv.y);
         const bool backface = (__float_as_uint(hn.w) & 2u) != 0u;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
     // capped grid striding over the queue (its length is only known here; see MAT_GRID in material.hip)
     for (uint32_t gd = blockIdx.x * MISC_BLOCK + threadIdx.x; gd < qlen; gd += gridDim.x * MISC_BLOCK) {
         const uint32_t gid = qs.q[FLX_Q_RAYGEN][gd];
-        uint32_t seed = __float_as_uint(rd4(st.at(S_THR, gid)).w);
+        uint32_t seed = __float_as_uint(rd4t(st.at(S_THR, gid)).w);
         // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
         // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
         const uint32_t localIdx = (*fr.currPixelIdx + gd) % fr.localPixels;
