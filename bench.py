@@ -364,6 +364,7 @@ def main():
     # ---- multi-GPU: gather the radiance tiles over RCCL (outside the timed region)
     gather_ms = None
     native_hung = False
+    native_err = native_ok = None
     if use_dist:
         lp = ctxs[0].local_pixels()
         maxlp = (args.width * args.height + world - 1) // world
@@ -379,7 +380,7 @@ def main():
         # the same gather through the library's own RCCL group (flx_group_init / flx_gather: what the C++ host uses), id shipped by torch
         # It runs under a watchdog thread: the bench line must come out even if this second RCCL communicator cannot be formed on some
         # node (nothing above N = 1 could be tested in the build environment); a failure is REPORTED in the line, never silently skipped.
-        native_ms = native_ok = native_err = None
+        native_ms = native_ok = native_err = native_seen = None
         native_hung = False
         if C == 1 and os.environ.get("FLX_NATIVE_GATHER", "1") != "0":
             import threading
@@ -400,6 +401,7 @@ def main():
                     if id_err or not any(id_bytes):
                         raise RuntimeError(id_err or "no unique id")
                     ctxs[0].group_init(rank, world, id_bytes)
+                    res["nranks_seen"] = ctxs[0].group_info()[0]          # ncclCommCount of the library's own communicator
                     n0 = time.perf_counter()
                     img = ctxs[0].gather(0)
                     res["ms"] = (time.perf_counter() - n0) * 1e3
@@ -415,6 +417,7 @@ def main():
                 native_err = "flx_group_init / flx_gather did not return within the watchdog timeout"
             else:
                 native_ms, native_ok, native_err = res.get("ms"), res.get("ok"), res.get("err")
+                native_seen = res.get("nranks_seen")
             if rank == 0 and native_ok is False:
                 native_err = "flx_gather differs from torch.distributed.gather"
         gather_ok = None
@@ -474,6 +477,7 @@ def main():
             line["gather_matches_read_pixels"] = gather_ok
             line["gather_ms_native_rccl"] = native_ms
             line["gather_native_matches_torch"] = native_ok
+            line["gather_native_nranks_seen"] = native_seen
             if native_err:
                 line["gather_native_error"] = native_err
         if world == 1 and not args.no_cpu_baseline:
@@ -482,11 +486,17 @@ def main():
                 line["cpu_baseline_port"] = cpu_baseline(d, p, env, budget_s=8.0, force_kind="port")
         print(json.dumps(line), flush=True)
     if use_dist:
-        if native_hung:                  # a thread is stuck inside RCCL: leave without the collective tear-down
+        # The native gather (flx_group_init / flx_gather: the code the C++ host runs) failing is a FAILED run: the line above carries the
+        # reason, and the exit status must not say "ok".  Hung: a thread is stuck inside RCCL, leave without the collective tear-down.
+        native_failed = bool(native_hung or native_err or native_ok is False)
+        if native_hung:
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
         dist.barrier()
         dist.destroy_process_group()
+        if native_failed:
+            sys.stderr.write(f"[bench] rank {rank}: native RCCL gather failed: {native_err}\n")
+            sys.exit(3)
 
 
 if __name__ == "__main__":

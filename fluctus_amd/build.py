@@ -35,7 +35,7 @@ def _headers():
 
 def build_host(force=False):
     src = sorted(glob.glob(os.path.join(PKG, "host", "*.cpp")))
-    dep = src + glob.glob(os.path.join(PKG, "host", "*.hpp")) + _headers()
+    dep = src + glob.glob(os.path.join(PKG, "host", "*.hpp")) + _headers() + [os.path.join(PKG, "csrc", "flx_wide.h")]   # host_capi.cpp includes the wide-tree builder
     out = os.path.join(PKG, "libfluctus_host.so")
     if force or _stale(out, dep):
         _run(["g++"] + CXX_FLAGS + ["-fopenmp"] + src + ["-o", out, "-ldl", "-lz"])
@@ -71,6 +71,17 @@ def build_hip(force=False):
     return out
 
 
+def build_test_libs(force=False):
+    """Test infrastructure only: tests/fake_rccl.cpp (a librccl stand-in that moves tiles between host threads on one device, selected
+    with FLX_RCCL_LIB; lets the N > 1 branches of flx_gather run on a 1-GPU box)."""
+    src = [os.path.join(ROOT, "tests", "fake_rccl.cpp")]
+    out = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
+    if force or _stale(out, src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run(["g++"] + CXX_FLAGS + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + src + ["-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    return out
+
+
 def build_all(force=False):
     """Build whatever is stale.  Serialised with a file lock: with `torch.distributed.run` every rank calls this at start-up."""
     import fcntl
@@ -79,6 +90,6 @@ def build_all(force=False):
     with open(os.path.join(PKG, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]
+            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force), build_test_libs(force)]
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -301,7 +301,8 @@ int flx_destroy(flx_ctx *c)
 }
 
 uint32_t flx_num_tasks(flx_ctx *c) { return c->numTasks; }
-void *flx_stream(flx_ctx *c) { return (void *)c->stream; }
+// (an interop caller enqueues its own work behind ours on this stream: a deferred flx_wf_logic / flx_wf_raygen must be in it by then)
+void *flx_stream(flx_ctx *c) { (void)settle(c); return (void *)c->stream; }
 
 // ---- scene upload: reference wire arrays -> traversal layout -------------------------------
 int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t *indices, size_t nidx,
@@ -484,6 +485,12 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
     c->sc.wnodes = dW; c->sc.wleaf = dL; c->sc.wrootRef = wide.rootRef;
+    {   // flx_trace4.h, WRay::setup: which clamp of 1 / dir keeps (o - orig) * dinv finite for this scene
+        const flx_node &r0 = nodes[0];
+        const float ext[6] = {r0.bmin.x, r0.bmin.y, r0.bmin.z, r0.bmax.x, r0.bmax.y, r0.bmax.z};
+        float m = 0.0f; for (float v : ext) m = std::fabs(v) > m ? std::fabs(v) : m;
+        c->sc.wideClamp = m < 67108864.0f ? FLX_WIDE_DINV_MAX : FLX_WIDE_DINV_FAR;
+    }
     // the exactness argument of the wide any-hit traversal needs nested boxes (flx_wide.h); a tree without them (no builder of
     // ours or of the reference produces one) is traversed with the binary kernels
     c->wideOK = wide.nested;
@@ -816,19 +823,31 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     std::string err;
 };
 Rccl g_rccl;
 bool rccl_load()
 {
     if (g_rccl.dl) return true;
-    void *dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // FLX_RCCL_LIB=<path>: bind another library with the same entry points (tests/fake_rccl.cpp moves the tiles between host threads
+    // on ONE device, so that the N > 1 send / receive code below runs on a 1-GPU box; never set in production)
+    void *dl = nullptr;
+    const char *over = getenv("FLX_RCCL_LIB");
+    if (over && *over) {
+        dl = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!dl) { g_rccl.err = std::string("FLX_RCCL_LIB=") + over + " not loadable: " + dlerror(); return false; }
+    }
+    if (!dl) dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!dl) dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!dl) dl = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!dl) { g_rccl.err = std::string("librccl.so.1 not loadable: ") + dlerror(); return false; }
 #define RSYM(field, name) g_rccl.field = (decltype(g_rccl.field))dlsym(dl, #name); if (!g_rccl.field) { g_rccl.err = "librccl: missing symbol " #name; dlclose(dl); return false; }
     RSYM(GetUniqueId, ncclGetUniqueId) RSYM(CommInitRank, ncclCommInitRank) RSYM(CommInitAll, ncclCommInitAll) RSYM(CommDestroy, ncclCommDestroy)
     RSYM(Send, ncclSend) RSYM(Recv, ncclRecv) RSYM(GroupStart, ncclGroupStart) RSYM(GroupEnd, ncclGroupEnd) RSYM(GetErrorString, ncclGetErrorString)
+    RSYM(CommCount, ncclCommCount) RSYM(CommUserRank, ncclCommUserRank) RSYM(CommAbort, ncclCommAbort)
 #undef RSYM
     g_rccl.dl = dl;
     return true;
@@ -856,6 +875,21 @@ int flx_group_destroy(flx_ctx *c)
     return 0;
 }
 
+static int gatherBuffers(flx_ctx *root, uint32_t nranks);
+
+// Calls between ncclGroupStart and ncclGroupEnd: remember the first failure and keep going, so that the group is ALWAYS closed
+// (returning with it open would leave every later collective of the process inside a dangling group).
+struct NcclGroup {
+    ncclResult_t first = ncclSuccess; const char *what = nullptr;
+    void operator()(ncclResult_t r, const char *w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } }
+    int fail(flx_ctx *c) const { if (first == ncclSuccess) return 0; c->err = std::string(what) + ": " + g_rccl.GetErrorString(first); return 1; }
+};
+#define NCCLTRY(g, expr) (g)((expr), #expr)
+
+// a rank that cannot take part in a collective its peers have already entered tears the communicator down, so that they fail
+// instead of waiting for it forever
+static void abortGroup(flx_ctx *c) { if (c->comm && g_rccl.dl) { (void)hipSetDevice(c->device); (void)g_rccl.CommAbort(c->comm); } c->comm = nullptr; }
+
 int flx_group_init(flx_ctx *c, uint32_t rank, uint32_t nranks, const void *id128)
 {
     MUTATES(c);
@@ -865,7 +899,26 @@ int flx_group_init(flx_ctx *c, uint32_t rank, uint32_t nranks, const void *id128
     flx_group_destroy(c);
     ncclUniqueId id; memcpy(&id, id128, sizeof(id));
     NCCLCHK(c, g_rccl.CommInitRank(&c->comm, (int)nranks, id, (int)rank));
-    return flx_set_partition(c, rank, nranks);
+    if (flx_set_partition(c, rank, nranks)) return 1;
+    // Any rank may be asked to be the root of flx_gather: its staging buffers are allocated HERE, where every rank allocates the same
+    // amount and an out-of-memory condition is an error of this call on every rank alike -- not inside the collective, where a root
+    // that fails before posting its receives would leave the peers blocked in ncclSend.  (A later flx_set_params with a larger frame
+    // re-allocates in flx_gather; if THAT fails the root aborts the communicator.)
+    if (c->haveParams && gatherBuffers(c, nranks)) return 1;
+    return 0;
+}
+
+int flx_group_info(flx_ctx *c, uint32_t *out2)
+{
+    NEED(c, out2, "flx_group_info: null");
+    out2[0] = out2[1] = 0;
+    if (c->commShared) { out2[0] = c->fr.nranks; out2[1] = c->fr.rank; return 0; }
+    NEED(c, c->comm, "flx_group_info: no group");
+    int n = 0, r = 0;
+    NCCLCHK(c, g_rccl.CommCount(c->comm, &n));
+    NCCLCHK(c, g_rccl.CommUserRank(c->comm, &r));
+    out2[0] = (uint32_t)n; out2[1] = (uint32_t)r;
+    return 0;
 }
 
 int flx_group_init_local(flx_ctx **ctxs, uint32_t n)
@@ -875,6 +928,8 @@ int flx_group_init_local(flx_ctx **ctxs, uint32_t n)
     bool distinct = true;
     for (uint32_t i = 0; i < n; i++) { NEED(c0, ctxs[i], "flx_group_init_local: null context"); for (uint32_t j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false; }
     for (uint32_t i = 0; i < n; i++) { MUTATES(ctxs[i]); flx_group_destroy(ctxs[i]); }
+    // (with a stand-in transport bound through FLX_RCCL_LIB the communicator path is taken whatever the devices are: tests)
+    { const char *over = getenv("FLX_RCCL_LIB"); if (over && *over) distinct = true; }
     if (distinct) {
         NEED(c0, rccl_load(), g_rccl.err);
         std::vector<ncclComm_t> comms(n); std::vector<int> devs(n);
@@ -915,7 +970,10 @@ static int gatherFinish(flx_ctx *root, uint32_t nranks, float *out_host)
     return 0;
 }
 
-// multi-process: every rank of the communicator calls this; out_host (width*height float4) is written on `root` only
+// multi-process: every rank of the communicator calls this; out_host (width*height float4) is written on `root` only.
+// Error paths: argument errors that every rank sees alike (no group, no frame, root out of range) return before anything is posted.
+// Past that point the peers are, or soon will be, blocked in their ncclSend, so the root either posts every matching receive
+// (also when its own output pointer is null: the tiles are received and the error reported afterwards) or aborts the communicator.
 int flx_gather(flx_ctx *c, uint32_t root, float *out_host)
 {
     MUTATES(c);
@@ -925,22 +983,26 @@ int flx_gather(flx_ctx *c, uint32_t root, float *out_host)
     NEED(c, root < R, "flx_gather: bad root");
     HIPCHK(c, hipSetDevice(c->device));
     if (me != root) {
-        NCCLCHK(c, g_rccl.GroupStart());
-        NCCLCHK(c, g_rccl.Send(c->fr.pixels, (size_t)tilePixels(npix, me, R) * 4, ncclFloat32, (int)root, c->comm, c->stream));
-        NCCLCHK(c, g_rccl.GroupEnd());
+        NcclGroup g;
+        NCCLTRY(g, g_rccl.GroupStart());
+        NCCLTRY(g, g_rccl.Send(c->fr.pixels, (size_t)tilePixels(npix, me, R) * 4, ncclFloat32, (int)root, c->comm, c->stream));
+        NCCLTRY(g, g_rccl.GroupEnd());
+        if (g.fail(c)) return 1;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
-    NEED(c, out_host, "flx_gather: null output on the root");
-    if (gatherBuffers(c, R)) return 1;
+    if (gatherBuffers(c, R)) { const std::string why = c->err; abortGroup(c); c->err = "flx_gather: root cannot allocate its staging buffers (" + why + "); communicator aborted"; return 1; }
     const size_t maxlp = tilePixels(npix, 0, R);
-    NCCLCHK(c, g_rccl.GroupStart());
+    NcclGroup g;
+    NCCLTRY(g, g_rccl.GroupStart());
     for (uint32_t r = 0; r < R; r++) {
         if (r == me) continue;
-        NCCLCHK(c, g_rccl.Recv(c->gatherStage + (size_t)r * maxlp * 4, (size_t)tilePixels(npix, r, R) * 4, ncclFloat32, (int)r, c->comm, c->stream));
+        NCCLTRY(g, g_rccl.Recv(c->gatherStage + (size_t)r * maxlp * 4, (size_t)tilePixels(npix, r, R) * 4, ncclFloat32, (int)r, c->comm, c->stream));
     }
-    NCCLCHK(c, g_rccl.GroupEnd());
+    NCCLTRY(g, g_rccl.GroupEnd());
+    if (g.fail(c)) return 1;
     HIPCHK(c, hipMemcpyAsync(c->gatherStage + (size_t)me * maxlp * 4, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
+    if (!out_host) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->err = "flx_gather: null output on the root (the tiles were received and dropped)"; return 1; }
     return gatherFinish(c, R, out_host);
 }
 
@@ -956,19 +1018,23 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
         NEED(rc, (ctxs[i]->comm != nullptr) != ctxs[i]->commShared, "flx_gather_local: no group (flx_group_init_local first)");
     }
     HIPCHK(rc, hipSetDevice(rc->device));
-    if (gatherBuffers(rc, n)) return 1;
+    if (gatherBuffers(rc, n)) return 1;                                 // nothing posted yet: a plain error
     const uint32_t npix = rc->params.width * rc->params.height;
     const size_t maxlp = tilePixels(npix, 0, n);
     if (rc->comm) {
-        NCCLCHK(rc, g_rccl.GroupStart());
-        for (uint32_t r = 0; r < n; r++) {
+        NcclGroup g; hipError_t he = hipSuccess;
+        NCCLTRY(g, g_rccl.GroupStart());
+        for (uint32_t r = 0; r < n && he == hipSuccess; r++) {
             if (r == root) continue;
-            HIPCHK(rc, hipSetDevice(ctxs[r]->device));
-            NCCLCHK(rc, g_rccl.Send(ctxs[r]->fr.pixels, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)root, ctxs[r]->comm, ctxs[r]->stream));
-            HIPCHK(rc, hipSetDevice(rc->device));
-            NCCLCHK(rc, g_rccl.Recv(rc->gatherStage + (size_t)r * maxlp * 4, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)r, rc->comm, rc->stream));
+            if ((he = hipSetDevice(ctxs[r]->device)) != hipSuccess) break;
+            NCCLTRY(g, g_rccl.Send(ctxs[r]->fr.pixels, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)root, ctxs[r]->comm, ctxs[r]->stream));
+            if ((he = hipSetDevice(rc->device)) != hipSuccess) break;
+            NCCLTRY(g, g_rccl.Recv(rc->gatherStage + (size_t)r * maxlp * 4, (size_t)ctxs[r]->fr.localPixels * 4, ncclFloat32, (int)r, rc->comm, rc->stream));
         }
-        NCCLCHK(rc, g_rccl.GroupEnd());
+        NCCLTRY(g, g_rccl.GroupEnd());                                  // always closed, whatever happened above
+        (void)hipSetDevice(rc->device);
+        if (he != hipSuccess) { rc->err = std::string("flx_gather_local: hipSetDevice: ") + hipGetErrorString(he); return 1; }
+        if (g.fail(rc)) return 1;
         for (uint32_t r = 0; r < n; r++) if (r != root) { HIPCHK(rc, hipSetDevice(ctxs[r]->device)); HIPCHK(rc, hipStreamSynchronize(ctxs[r]->stream)); }
         HIPCHK(rc, hipSetDevice(rc->device));
     } else {

@@ -93,6 +93,7 @@ struct Scene {
     const void *wnodes;
     const float4 *wleaf;
     uint32_t wrootRef;
+    float wideClamp;              // bound of |1 / dir| in the wide node test: 2^100, or 2^64 for scenes beyond +-2^26 (flx_trace4.h: WRay::setup)
     // environment map
     const float4 *envRGBA;
     const float *probTable, *pdfTable;

@@ -66,7 +66,19 @@ __device__ __forceinline__ float fma_(float a, float b, float c) { return __buil
 __device__ __forceinline__ float max3_(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ float min3_(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 
+// bytes {b3 b2 b1 b0} of a packed plane dword -> two packed binary16 values 0x6400 | b = 1024 + b (W4_MIX)
+typedef _Float16 h2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2f halves01(uint32_t q) { return __builtin_bit_cast(h2f, __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u)); }
+__device__ __forceinline__ h2f halves23(uint32_t q) { return __builtin_bit_cast(h2f, __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u)); }
+#ifndef W4_MIX
+#define W4_MIX 0
+#endif
+#ifndef W4_FOLD_E
+#define W4_FOLD_E 0
+#endif
+
 #define FLX_WIDE_DINV_MAX 1.2676506e30f          // 2^100
+#define FLX_WIDE_DINV_FAR 1.8446744e19f          // 2^64: the clamp of a ray whose origin lies beyond +-2^26
 
 // compare-exchange of (key, ref) pairs, ascending key
 #define FLX_CE(ka, ra, kb, rb) do { const bool sw_ = kb < ka; const float tk_ = sw_ ? kb : ka; const uint32_t tr_ = sw_ ? rb : ra; \
@@ -77,13 +89,21 @@ struct WRay {
     f3 orig, dir, dinv;            // dinv = the reference's native_recip(dir) (exact, may be +-inf): leaf boxes
     float dwx, dwy, dwz;           // dinv clamped to +-2^100: node test
     bool negx, negy, negz;
-    __device__ __forceinline__ void setup(f3 o, f3 d)
+    __device__ __forceinline__ void setup(f3 o, f3 d, float clampNear)
     {
         orig = o; dir = d;
         dinv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        dwx = fminf_(fmaxf_(dinv.x, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
-        dwy = fminf_(fmaxf_(dinv.y, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
-        dwz = fminf_(fmaxf_(dinv.z, -FLX_WIDE_DINV_MAX), FLX_WIDE_DINV_MAX);
+        // od = (o - orig) * dw must stay finite: an infinite od makes od - e a NaN, every comparison false and the child culled, and
+        // the any-hit sort uses +inf as its miss sentinel.  clampNear is 2^100 when every node coordinate lies inside +-2^26 (every
+        // real scene; flx_upload_scene) and the origin does too: |o - orig| < 2^27, the product stays below 2^127.  Otherwise -- node
+        // coordinates are bounded by 2^62 at upload (flx_wide.h) -- the clamp is 2^64: |o - orig| < 2^63.  (The clamp only has to
+        // switch an axis off for a ray that runs parallel to it INSIDE the node's slab: e >= 2^-13 s |dw| must exceed every entry
+        // distance of the other axes, header comment; 2^64 still does for nodes larger than 2^-37 of the scene.)
+        const float far = fmaxf_(fmaxf_(absf(o.x), absf(o.y)), absf(o.z));
+        const float lim = far < 67108864.0f ? clampNear : FLX_WIDE_DINV_FAR;
+        dwx = fminf_(fmaxf_(dinv.x, -lim), lim);
+        dwy = fminf_(fmaxf_(dinv.y, -lim), lim);
+        dwz = fminf_(fmaxf_(dinv.z, -lim), lim);
         negx = (__float_as_uint(dwx) >> 31) != 0u; negy = (__float_as_uint(dwy) >> 31) != 0u; negz = (__float_as_uint(dwz) >> 31) != 0u;
     }
 };
@@ -105,10 +125,30 @@ __device__ __forceinline__ void wide_node_visit(const float4 *wn, WStack &stk, c
     // per-axis slope / offset of t(q) = q * sd + od, and the conservative shift e (header comment)
     const float sdx = n0.w * r.dwx, sdy = n1.x * r.dwy, sdz = n1.y * r.dwz;
     const float odx = (n0.x - r.orig.x) * r.dwx, ody = (n0.y - r.orig.y) * r.dwy, odz = (n0.z - r.orig.z) * r.dwz;
+#if W4_MIX
+    // Planes as packed halves H = 1024 + q (0x6400 | q: exact in binary16 AND in binary32), one v_perm_b32 per two planes and ONE
+    // v_fma_mix_f32 per plane (the half -> float conversion is part of the instruction) instead of v_cvt_f32_ubyteN + v_fma_f32:
+    //     t(q) = fma(H, sd, od - 1024 sd).
+    // Error: od carries 2u|od| (subtract, multiply), od2 = fma(-1024, sd, od) adds u|od2| <= u(|od| + 1024|sd|), the final rounding
+    // u|t| <= u(|od| + 255|sd|): |t - real| <= u(4|od| + 1279|sd|); the reference's T(b) is within 2u(|od| + 255|sd|) of the same
+    // real number.  e = 2^-20 |od| + 2^-21 384 |sd| = 16u|od| + 3072u|sd| covers the sum of both (6u|od| + 1789u|sd|).
+    const float mx = fma_(absf(sdx), 192.0f, absf(odx)), my = fma_(absf(sdy), 192.0f, absf(ody)), mz = fma_(absf(sdz), 192.0f, absf(odz));
+    const float bx = fma_(sdx, -1024.0f, odx), by = fma_(sdy, -1024.0f, ody), bz = fma_(sdz, -1024.0f, odz);
+    const float onx = fma_(mx, -9.53674316e-7f, bx), ofx = fma_(mx, 9.53674316e-7f, bx);          // -+ 2^-20 m
+    const float ony = fma_(my, -9.53674316e-7f, by), ofy = fma_(my, 9.53674316e-7f, by);
+    const float onz = fma_(mz, -9.53674316e-7f, bz), ofz = fma_(mz, 9.53674316e-7f, bz);
+#elif W4_FOLD_E
+    // e = 2^-21 (|od| + 256 |sd|) folded into the shifted offsets: one fma each instead of a multiply and an add / subtract
+    const float mx = fma_(absf(sdx), 256.0f, absf(odx)), my = fma_(absf(sdy), 256.0f, absf(ody)), mz = fma_(absf(sdz), 256.0f, absf(odz));
+    const float onx = fma_(mx, -4.76837158e-7f, odx), ofx = fma_(mx, 4.76837158e-7f, odx);
+    const float ony = fma_(my, -4.76837158e-7f, ody), ofy = fma_(my, 4.76837158e-7f, ody);
+    const float onz = fma_(mz, -4.76837158e-7f, odz), ofz = fma_(mz, 4.76837158e-7f, odz);
+#else
     const float ex = 4.76837158e-7f * fma_(absf(sdx), 256.0f, absf(odx));      // 2^-21 (|od| + 256 |sd|)
     const float ey = 4.76837158e-7f * fma_(absf(sdy), 256.0f, absf(ody));
     const float ez = 4.76837158e-7f * fma_(absf(sdz), 256.0f, absf(odz));
     const float onx = odx - ex, ofx = odx + ex, ony = ody - ey, ofy = ody + ey, onz = odz - ez, ofz = odz + ez;
+#endif
     const uint32_t qlox = __float_as_uint(n2.z), qloy = __float_as_uint(n2.w), qloz = __float_as_uint(n3.x);
     const uint32_t qhix = __float_as_uint(n3.y), qhiy = __float_as_uint(n3.z), qhiz = __float_as_uint(n3.w);
     const uint32_t qnx = r.negx ? qhix : qlox, qfx = r.negx ? qlox : qhix;
@@ -117,6 +157,20 @@ __device__ __forceinline__ void wide_node_visit(const float4 *wn, WStack &stk, c
     uint32_t r0 = __float_as_uint(n1.z), r1 = __float_as_uint(n1.w), r2 = __float_as_uint(n2.x), r3 = __float_as_uint(n2.y);
     // tnear <= tfar, tfar >= 0, tnear < tMax: the reference's three conditions (src/intersect.cl:55-59).  Unused child slots point
     // at a dummy leaf that cannot be hit (flx_wide.h), so no validity test is needed here.
+#if W4_MIX
+    const h2f hnx0 = halves01(qnx), hnx1 = halves23(qnx), hny0 = halves01(qny), hny1 = halves23(qny), hnz0 = halves01(qnz), hnz1 = halves23(qnz);
+    const h2f hfx0 = halves01(qfx), hfx1 = halves23(qfx), hfy0 = halves01(qfy), hfy1 = halves23(qfy), hfz0 = halves01(qfz), hfz1 = halves23(qfz);
+#define FLX_CHILD(P, C, KEY, HIT) \
+    { const float tn = max3_(fma_((float)hnx##P.C, sdx, onx), fma_((float)hny##P.C, sdy, ony), fma_((float)hnz##P.C, sdz, onz)); \
+      const float tf = min3_(fma_((float)hfx##P.C, sdx, ofx), fma_((float)hfy##P.C, sdy, ofy), fma_((float)hfz##P.C, sdz, ofz)); \
+      HIT = (tn <= tf) && (tf >= 0.0f) && (tn < tbest); KEY = tn; }
+    float k0, k1, k2, k3; bool h0, h1, h2, h3;
+    FLX_CHILD(0, x, k0, h0)
+    FLX_CHILD(0, y, k1, h1)
+    FLX_CHILD(1, x, k2, h2)
+    FLX_CHILD(1, y, k3, h3)
+#undef FLX_CHILD
+#else
 #define FLX_CHILD(UB, KEY, HIT) \
     { const float tn = max3_(fma_(UB(qnx), sdx, onx), fma_(UB(qny), sdy, ony), fma_(UB(qnz), sdz, onz)); \
       const float tf = min3_(fma_(UB(qfx), sdx, ofx), fma_(UB(qfy), sdy, ofy), fma_(UB(qfz), sdz, ofz)); \
@@ -127,6 +181,7 @@ __device__ __forceinline__ void wide_node_visit(const float4 *wn, WStack &stk, c
     FLX_CHILD(ub2, k2, h2)
     FLX_CHILD(ub3, k3, h3)
 #undef FLX_CHILD
+#endif
     stk.reserve(sp);
     if (ANY_HIT && ANY_ORDER == 1) {
         const float INF = __builtin_huge_valf();
@@ -188,7 +243,7 @@ __device__ __forceinline__ bool traverse4(const Scene &sc, WStack &stk, f3 orig,
 {
 #define FLX_WAVE_TICK(k) do { if (STATS && wstats) { const uint64_t m_ = __ballot(true); \
         if (lane_id() == (uint32_t)__ffsll((long long)m_) - 1u) atomicAdd(&wstats[k], 1ull); } } while (0)
-    WRay r; r.setup(orig, dir);
+    WRay r; r.setup(orig, dir, sc.wideClamp);
     const float4 *wn = reinterpret_cast<const float4 *>(sc.wnodes);
     int sp = 0;
     uint32_t cur = sc.wrootRef;

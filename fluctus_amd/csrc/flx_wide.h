@@ -26,6 +26,7 @@ namespace flxw {
 #define FLX_WIDE_LEAF_BIT 0x80000000u
 #define FLX_WIDE_EMPTY    (FLX_WIDE_LEAF_BIT | 0u)   // unused child slot = the dummy leaf at offset 0 of the leaf data (cannot be hit)
 #define FLX_WIDE_OFF_MASK 0x7FFFFFFFu
+#define FLX_WIDE_COORD_MAX 4.611686e18f          // 2^62: largest |coordinate| of a node box the wide tree accepts (flx_trace4.h: WRay::setup)
 
 // 64 B, 64-B aligned.  Plane k of child c on axis a:  o[a] + q * s[a],  q = byte c of qlo[a] / qhi[a].
 struct WNode {
@@ -90,12 +91,19 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
                 const uint32_t ti = indices[n.iStartOrRight + k];
                 if (ti >= ntris) return fail("wide tree: triangle index out of range");
                 const flx_triangle &t = tris[ti];
+                const float pc[9] = {t.v0.p.x, t.v0.p.y, t.v0.p.z, t.v1.p.x, t.v1.p.y, t.v1.p.z, t.v2.p.x, t.v2.p.y, t.v2.p.z};
+                for (float v : pc) if (!std::isfinite(v)) return fail("wide tree: triangle with a NaN or infinite vertex");
                 int idx = (int)ti; float fi; memcpy(&fi, &idx, 4);
                 out.leafdata.push_back({t.v0.p.x, t.v0.p.y, t.v0.p.z, fi});
                 out.leafdata.push_back({t.v1.p.x, t.v1.p.y, t.v1.p.z, 0.0f});
                 out.leafdata.push_back({t.v2.p.x, t.v2.p.y, t.v2.p.z, 0.0f});
             }
         }
+    }
+    {
+        const flx_node &r0 = nodes[0];
+        const float rb[6] = {r0.bmin.x, r0.bmin.y, r0.bmin.z, r0.bmax.x, r0.bmax.y, r0.bmax.z};
+        for (float v : rb) if (!std::isfinite(v) || std::fabs(v) > FLX_WIDE_COORD_MAX) return fail("wide tree: root box not finite or beyond +-2^62");
     }
     if (nodes[0].nPrims) {               // the whole scene is one leaf
         out.rootRef = leafRef[0]; out.maxStack = 1;
@@ -184,6 +192,10 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
             for (int a = 0; a < 3; a++) {
                 if (!(cmin[k][a] >= omin[a]) || !(cmax[k][a] <= omax[a])) out.nested = false;
                 if (!(cmin[k][a] <= cmax[k][a])) return fail("wide tree: inverted or NaN child box");
+                // infinite bounds pass the comparison above; the grid below needs finite extents (log2 of inf is undefined behaviour
+                // when converted to int), and FLX_WIDE_COORD_MAX keeps (o - orig) * dinv of the node test finite (flx_trace4.h)
+                if (!std::isfinite(cmin[k][a]) || !std::isfinite(cmax[k][a]) || std::fabs(cmin[k][a]) > FLX_WIDE_COORD_MAX || std::fabs(cmax[k][a]) > FLX_WIDE_COORD_MAX)
+                    return fail("wide tree: node box not finite or beyond +-2^62");
             }
         }
         // grid: origin = min over the children, per-axis power-of-two scale with o + 255 s >= max over the children

@@ -18,7 +18,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_wf_reset", "flx_wf_raygen", "flx_wf_extend", "flx_wf_shadow", "flx_wf_logic", "flx_wf_materials",
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
-           "flx_copy_pixels_to_device", "flx_stream", "flx_group_unique_id", "flx_group_init", "flx_group_init_local", "flx_gather", "flx_gather_local", "flx_group_destroy", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
+           "flx_copy_pixels_to_device", "flx_stream", "flx_group_unique_id", "flx_group_init", "flx_group_init_local", "flx_gather", "flx_gather_local", "flx_group_destroy", "flx_group_info", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
            "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_get_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
@@ -169,6 +169,12 @@ class HipContext:
         """One process per GPU: ncclCommInitRank + the pixel partition.  unique_id: the 128 bytes of group_unique_id() made on rank 0."""
         buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
         self._chk(self.L.flx_group_init(self.h, C.c_uint32(rank), C.c_uint32(nranks), buf))
+
+    def group_info(self):
+        """(ncclCommCount, ncclCommUserRank) as the communicator itself reports them."""
+        out = (C.c_uint32 * 2)()
+        self._chk(self.L.flx_group_info(self.h, out))
+        return int(out[0]), int(out[1])
 
     def gather(self, root=0):
         """Collective over the group: returns the full (width*height, 4) accumulation image on `root`, None elsewhere."""

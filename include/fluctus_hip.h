@@ -143,6 +143,8 @@ int flx_group_init_local(flx_ctx **ctxs, uint32_t n);
 int flx_gather(flx_ctx *ctx, uint32_t root, float *out_rgba_host);
 int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_rgba_host);
 int flx_group_destroy(flx_ctx *ctx);
+/* what the communicator itself reports: out2 = {ncclCommCount, ncclCommUserRank} (a same-device local group reports its partition) */
+int flx_group_info(flx_ctx *ctx, uint32_t *out2);
 
 /* ---- measurement.  Per-kernel HIP-event timing on the context's stream (the reference attaches
  * cl::Events to the two trace kernels, src/clcontext.cpp:673-701,780,786).  kernel ids: */

@@ -28,7 +28,7 @@ HIT_COLS = [COL.P, COL.P + 1, COL.P + 2, COL.N, COL.N + 1, COL.N + 2, COL.UV, CO
 def _report(name, payload):
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r02_wide_flips.json")
+    path = os.path.join(out_dir, "r03_wide_flips.json")
     try:
         j = json.load(open(path))
     except Exception:
@@ -237,3 +237,73 @@ def test_wide_vs_binary_kernels_on_device_full_size(workload):
     _report(f"wide_vs_binary_{workload}", {"extension_rays_compared": rays, "hit_index_flips": flips, "flip_rate": flips / max(1, rays),
                                            "shadow_rays_compared_bit_exact": sh, "scene_info": gw.scene_info()})
     assert flips <= FLIP_BUDGET * rays, (rays, flips)
+
+
+def _free_run_default_vs_oracle(workload, n, iterations, start_iterations=0):
+    """The shipped DEFAULT configuration (k_extend4 + k_shadow4, fused logic + material pass, two streams) free-running beside the
+    oracle.  Both sides run whole iterations on their own; after every extension launch the hit records are compared ray by ray and,
+    should a tie have flipped a hit index, the device continues from the ORACLE's records (tests/test_gpu_wide.py's resync pattern),
+    so one flip cannot fork the two runs and everything else stays comparable bit for bit: queue counters after every logic /
+    raygen / material step, the extension queue as a set, the whole path state after every extension AND every shadow launch,
+    the framebuffer at the end.  Returns (rays, flips)."""
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    npix = int(p["width"]) * int(p["height"])
+    g, o = _ctxs(d, p, n, env=env)
+    assert g.get_option("extend_tree") == 4 and g.get_option("shadow_tree") == 4 and g.get_option("fuse") == 1 and g.get_option("overlap") == 2
+    for it in range(start_iterations):                  # device alone (cheap), then the oracle takes the state over ...
+        cnt = driver.benchmark_iteration(g, npix)
+        o.pixel_index_update(npix, int(cnt[Q.RAYGEN]))   # ... the pixel cursor included (replayed: it is host-side state of both)
+    if start_iterations:
+        common.sync(o, g)
+    rays = flips = 0
+    for it in range(iterations):
+        for c in (g, o):
+            c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+        cg, co = g.get_counters(), o.get_counters(); g.finish()
+        cg, co = np.array(cg, copy=True), np.array(co, copy=True)
+        assert (cg == co).all(), f"{workload} it{it}: counters {cg} vs {co}"
+        ne = int(co[Q.EXTENSION])
+        qo = o.queue_read(Q.EXTENSION)[:ne]
+        assert np.array_equal(np.sort(g.queue_read(Q.EXTENSION)[:ne]), np.sort(qo)), f"{workload} it{it}: extension queues hold different paths"
+        g.wf_extend(); o.wf_extend(); g.finish()
+        sg, so = g.state_export(), o.state_export()
+        flip = np.zeros(sg.shape[1], bool)
+        flip[qo] = sg.view(np.uint32)[COL.HIT_I][qo] != so.view(np.uint32)[COL.HIT_I][qo]
+        rays += ne; flips += int(flip.sum())
+        fails = common.state_diff(sg, so, 0.0, 0.0, mask=~flip)
+        assert not fails, f"{workload} it{it} after extend: " + "; ".join(fails[:4])
+        if flip.any():
+            fr = np.nonzero(flip)[0]
+            assert np.allclose(sg[COL.HIT_T][fr], so[COL.HIT_T][fr], rtol=1e-5, atol=1e-6), f"{workload} it{it}: a flip that is not a tie in t"
+            g.state_import(so)
+        g.wf_shadow(); o.wf_shadow(); g.finish()
+        fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+        assert not fails, f"{workload} it{it} after shadow: " + "; ".join(fails[:4])
+        for c in (g, o):
+            c.clear_queues(); c.pixel_index_update(npix, int(co[Q.RAYGEN]))
+    if not start_iterations:
+        assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
+    g.close()
+    return rays, flips
+
+
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
+def test_default_path_free_run_vs_oracle_full_size(workload):
+    """BASELINE configs 1-3 at their full resolutions and bounce counts, 1 M paths, 10 whole iterations of the default path against the
+    ORACLE (not against the binary device kernel): state / counters / queues identical throughout, hit-index flips counted."""
+    n = 1 << 20
+    rays, flips = _free_run_default_vs_oracle(workload, n, 10)
+    _report(f"default_free_run_{workload}", {"paths": n, "iterations": 10, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips,
+                                             "flip_rate": flips / max(1, rays)})
+    assert rays == 10 * n
+    assert flips <= FLIP_BUDGET * rays, (rays, flips)
+
+
+def test_default_path_2160p_checkpoint_vs_oracle():
+    """BASELINE config 4's geometry (courtyard-proc, 3840x2160, 16 bounces): the device runs 20 iterations alone (deep paths in flight),
+    then two iterations in lockstep with the oracle as above."""
+    n = 1 << 20
+    rays, flips = _free_run_default_vs_oracle("courtyard-2160p", n, 2, start_iterations=20)
+    _report("default_2160p_checkpoint", {"paths": n, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips})
+    assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)

@@ -142,6 +142,23 @@ def test_wide_tree_degenerate_inputs():
     d.indices = np.arange(nt, dtype=np.uint32) + 1
     with pytest.raises(Exception, match="triangle index"):
         host.wide_tree_check(d)
+    # non-finite input (round 2's advisor): an infinite box passes `min <= max`, its extent is inf and the grid exponent would come out
+    # of log2(inf) converted to int; a NaN / inf vertex would be copied into a leaf block.  Both are refused with a message of their own,
+    # and so is a box beyond +-2^62, where (o - orig) / dir of the node test could overflow (flx_trace4.h: WRay::setup)
+    d.indices = np.arange(nt, dtype=np.uint32)
+    for val, where in ((np.inf, "bmax"), (-np.inf, "bmin"), (1e19, "bmax")):
+        bad = nodes.copy(); bad[4][where]["y"] = val; bad[0][where]["y"] = val; bad[2][where]["y"] = val
+        d.nodes = bad
+        with pytest.raises(Exception, match="not finite or beyond"):
+            host.wide_tree_check(d)
+    d.nodes = nodes
+    keep = d.tris.copy()
+    for val in (np.nan, np.inf):
+        d.tris = keep.copy(); d.tris[7]["v1"]["p"]["z"] = val
+        with pytest.raises(Exception, match="NaN or infinite vertex"):
+            host.wide_tree_check(d)
+    d.tris = keep
+    assert host.wide_tree_check(d)["leaves"] == nt
 
 
 def _soup(n, seed, long_share=0.3):
