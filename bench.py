@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--fuse", type=int, default=1, choices=(0, 1), help="logic + material kernels as one fused pass (default) or the separate kernels")
     ap.add_argument("--ext-order", type=int, default=-1, choices=(-1, 0, 1), help="fused pass: extension queue lists the continuing paths by path id (1) or in one segment per material queue (0); -1 = what flx_upload_scene chose")
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
+    ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
+    ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
@@ -205,6 +207,10 @@ def main():
         c_.set_option("node_layout", args.node_layout)
         c_.set_option("eager_bump", args.eager_bump)
         c_.set_option("fuse", args.fuse)
+        if args.refill_extend >= 0:
+            c_.set_option("refill_extend", args.refill_extend)
+        if args.refill_shadow >= 0:
+            c_.set_option("refill_shadow", args.refill_shadow)
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene

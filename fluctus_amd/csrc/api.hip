@@ -19,6 +19,8 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
+void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
+void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t, int);
@@ -88,6 +90,8 @@ struct flx_ctx {
     // 4 = the 4-wide quantised tree over the same leaves (flx_wide.h): any-hit bit-exact by construction, closest hit exact up to
     // visit-order ties
     int shadowTree = 4, extendTree = 4;
+    // persistent waves with lane refill for the 4-wide kernels (trace4r.hip): 0 = thread-per-ray kernels, n > 0 = refill when n lanes are idle
+    int refillExt = 0, refillShadow = 0;
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
@@ -601,7 +605,8 @@ int flx_wf_extend(flx_ctx *c)
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
-        if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
+        if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt);
+        else if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -632,7 +637,8 @@ int flx_wf_shadow(flx_ctx *c)
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
-        if (c->shadowTree == 4 && c->wideOK) launch_shadow4(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr);
+        if (c->shadowTree == 4 && c->wideOK && c->refillShadow > 0 && !c->statsOn) launch_shadow4r(s, c->st, c->qs, c->sc, c->params, spill, (uint32_t)c->numCUs, c->refillShadow);
+        else if (c->shadowTree == 4 && c->wideOK) launch_shadow4(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
@@ -1149,6 +1155,8 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
         return 0;
     }
+    if (name && strcmp(name, "refill_extend") == 0 && value >= 0 && (value & 0xFF) <= 64 && ((value >> 8) & 0xFF) <= 64 && (value >> 17) == 0) { MUTATES(c); c->refillExt = value; return 0; }
+    if (name && strcmp(name, "refill_shadow") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillShadow = value; return 0; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
@@ -1159,7 +1167,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;
     return 1;

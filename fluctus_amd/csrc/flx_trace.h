@@ -80,6 +80,7 @@ __device__ __forceinline__ bool light_quad(const flx_arealight &L, f3 orig, f3 d
 // shading attributes of the winning triangle interpolated at (u, v) (src/bvh.cl:271-279; the reference re-interpolates at
 // every commit, only the last one is observable), then the implicit area-light hit (src/wf_extrays.cl:28-29,
 // src/intersect.cl:124-155), pathLen += 1 and the 12 hit columns.  Shared by the binary and the 4-wide kernels.
+template <bool LIGHT_QUAD = true>
 __device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, const flx_render_params &p, uint32_t gid, f3 orig, f3 dir, float pathLenBits,
                                            float t, float u, float v, int tri, uint32_t &flags, int &matId)
 {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, con
         tu = uv.x; tv = uv.y;
         matId = __float_as_int(d.w);
     }
-    if (p.sampleImpl && p.useAreaLight) {
+    if (LIGHT_QUAD && p.sampleImpl && p.useAreaLight) {          // (LIGHT_QUAD false: a caller that knows the scene has no area light)
         if (light_quad(p.areaLight, orig, dir, &t)) {
             flags = 1u;
             P = orig + t * dir;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void alone_##NAME(float *out, const float *in)
     float s = in[64 + (threadIdx.x & 63)], o = in[128 + (threadIdx.x & 63)]; uint32_t q = __float_as_uint(in[192 + (threadIdx.x & 63)]); \
     const long long t0 = clock64(); \
     for (int r = 0; r < REPS; r++) asm volatile(R8(X0 "\n" X1 "\n" X2 "\n" X3 "\n" X0 "\n" X1 "\n" X2 "\n" X3 "\n") \
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "v"(o), "v"(q) : "vcc", "s20", "s21"); \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "v"(o), "v"(q) : "vcc", "scc", "s20", "s21"); \
     const long long t1 = clock64(); \
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(out)[1 << 18] = t1 - t0; \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; } \
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void pair_##NAME(float *out, const float *in) 
     float s = in[64 + (threadIdx.x & 63)], o = in[128 + (threadIdx.x & 63)]; uint32_t q = __float_as_uint(in[192 + (threadIdx.x & 63)]); \
     const long long t0 = clock64(); \
     for (int r = 0; r < REPS; r++) asm volatile(R8(X0 "\n v_fma_f32 %4, %4, %8, %9\n" X1 "\n v_fma_f32 %5, %5, %8, %9\n" X2 "\n v_fma_f32 %6, %6, %8, %9\n" X3 "\n v_fma_f32 %7, %7, %8, %9\n") \
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "v"(o), "v"(q) : "vcc", "s20", "s21"); \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "v"(o), "v"(q) : "vcc", "scc", "s20", "s21"); \
     const long long t1 = clock64(); \
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<long long *>(out)[1 << 18] = t1 - t0; \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; }
@@ -83,6 +83,7 @@ static double run(kern_t k, float *out, const float *in, int waves_per_simd)
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     float *out, *in;
     CHECK(hipMalloc(&out, 256 * 8 * 256 * sizeof(float) + (1 << 21) + 64));
     CHECK(hipMalloc(&in, 1024 * sizeof(float)));

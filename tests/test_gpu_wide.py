@@ -307,3 +307,31 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     rays, flips = _free_run_default_vs_oracle("courtyard-2160p", n, 2, start_iterations=20)
     _report("default_2160p_checkpoint", {"paths": n, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips})
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
+
+
+@pytest.mark.parametrize("workload,refill", [("kitchen", 16), ("conference", 8 | (16 << 8)), ("kitchen", 48 | (8 << 8)), ("courtyard-1440p", 16 | (24 << 8))])
+def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
+    """Persistent waves with lane refill (trace4r.hip) run the SAME per-ray code as k_extend4 / k_shadow4, whatever lane or wave a ray
+    lands on and whenever it is handed out: two contexts free-run the workload at 1 M paths, one with the thread-per-ray kernels, one with
+    the refill kernels (+ k_commit4); counters after every iteration, the final path state and every queue are identical, the
+    framebuffers within the atomic-order bound."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    ctx = []
+    for r in (0, refill):
+        g = HipContext(n)
+        g.set_option("refill_extend", r); g.set_option("refill_shadow", r)
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); driver.reset_renderer(g)
+        ctx.append(g)
+    a, b = ctx
+    assert b.get_option("refill_extend") == refill and a.get_option("refill_extend") == 0
+    for it in range(12):
+        ca, cb = driver.benchmark_iteration(a, npix), driver.benchmark_iteration(b, npix)
+        assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
+    fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+    assert not fails, "; ".join(fails[:5])
+    assert common.fb_close(a.read_pixels(0), b.read_pixels(0))
+    for g in ctx:
+        g.close()
