@@ -21,7 +21,8 @@ void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, c
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
 void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
-void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int);
+void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int);
+void launch_materialise(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t, int);
 uint32_t fused_queue_mask(int);
@@ -92,6 +93,10 @@ struct flx_ctx {
     int shadowTree = 4, extendTree = 4;
     // persistent waves with lane refill for the 4-wide kernels (trace4r.hip): 0 = thread-per-ray kernels, n > 0 = refill when n lanes are idle
     int refillExt = 0, refillShadow = 0;
+    // The persistent-wave extension kernel leaves RAW hit records (flx_trace.h): true from flx_wf_extend until they are committed -- by the
+    // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
+    // or by k_materialise as soon as any other entry point runs (settle; the calls of the steady-state loop set keepRaw first).
+    bool rawHits = false, keepRaw = false;
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
@@ -211,6 +216,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if (num_tasks == 0) { g_create_error = "flx_create: num_tasks must be > 0"; return 1; }
     flx_ctx *c = new flx_ctx();
     c->device = device; c->numTasks = num_tasks;
+    // A/B hooks for whole test-suite runs: the defaults of the refill_extend / refill_shadow options
+    if (const char *e = getenv("FLX_REFILL_EXTEND")) c->refillExt = atoi(e);
+    if (const char *e = getenv("FLX_REFILL_SHADOW")) c->refillShadow = atoi(e);
     auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     // (stream priorities were tried: a high-priority shadow stream keeps the extension kernel at its undisturbed 0.86 ms and inflates
@@ -560,10 +568,25 @@ static int runRaygen(flx_ctx *c)
     LAUNCHED(c);
     return 0;
 }
+// commit the RAW hit records the persistent-wave extension kernel left (trace4r.hip: k_materialise)
+static int materialise(flx_ctx *c)
+{
+    if (!c->rawHits) return 0;
+    c->rawHits = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    launch_materialise(c->stream, c->st, c->sc, c->params, (uint32_t)c->numCUs);
+    LAUNCHED(c);
+    return 0;
+}
 static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
+    // RAW hit records are committed by the fused pass itself when genRays follows in the same chain (logic.hip: k_logic<FUSE, RAW>); the plain
+    // kernel and a chain without genRays get them committed first
+    const int raw = (c->rawHits && fused != 0 && raygenFirst) ? 1 : 0;
+    if (!raw && materialise(c)) return 1;
+    c->rawHits = false;
     flushExt(c);                                       // logic's scan overwrites the source-queue counters
-    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, c->extOrder); }
+    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, c->extOrder, raw); }
     LAUNCHED(c);
     c->matQueuesEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -576,17 +599,22 @@ static uint32_t materialBits(const flx_ctx *c)
 // launch what flx_wf_logic / flx_wf_raygen deferred, as the separate kernels (the caller is not flx_wf_materials)
 static int settle(flx_ctx *c)
 {
+    const bool keep = c->keepRaw; c->keepRaw = false;
     const int pd = c->pend;
-    if (!pd) return 0;
+    if (!pd) return keep ? 0 : materialise(c);
     c->pend = 0;
     HIPCHK(c, hipSetDevice(c->device));
-    if (runLogic(c, c->pendFirst, 0, 0)) return 1;
+    if (runLogic(c, c->pendFirst, 0, 0)) return 1;     // (commits RAW hit records first)
     if (pd == 2 && runRaygen(c)) return 1;
     return 0;
 }
+// entry points of the steady-state loop that neither read nor write hit records: RAW ones may stay until the next fused logic pass
+#define KEEP_RAW(c) do { (c)->keepRaw = true; } while (0)
 int flx_wf_raygen(flx_ctx *c)
 {
+    KEEP_RAW(c);                                       // genRays reads no hit record (and its paths' records are dead: flx_device.h)
     if (c->pend == 1) {                                // deferred behind the deferred flx_wf_logic (its queue does not exist yet)
+        c->keepRaw = false;                            // (no settle on this path to consume it)
         MUTATES_DEFERRING(c); KEEP_CHAIN(c);
         c->pend = 2;
         return 0;
@@ -605,7 +633,7 @@ int flx_wf_extend(flx_ctx *c)
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
-        if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt);
+        if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) { launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt); c->rawHits = true; }
         else if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
@@ -629,6 +657,7 @@ int flx_wf_shadow(flx_ctx *c)
     // HBM-bound raygen and material kernels.
     const bool overlapped = c->overlapOK;
     const bool early = overlapped && c->overlap == 2 && c->logicChain;
+    KEEP_RAW(c);                                       // shadow rays: {shadowOrig, shadowDir} -> shadowRayBlocked
     READY(c);
     hipStream_t s = c->stream;
     if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, early ? c->evPostLogic : c->evPreExt, 0)); }
@@ -654,6 +683,7 @@ int flx_wf_shadow(flx_ctx *c)
 }
 int flx_wf_logic(flx_ctx *c, int first)
 {
+    KEEP_RAW(c);                                       // (runLogic commits RAW hit records, or hands them to the fused pass)
     READY(c);
     // fused with the material kernels if flx_wf_materials follows (see flx_ctx::fuse).  The fused scatter numbers the material
     // queues from zero, so they must be empty now (cleared since the last logic: the reference clears all queues every iteration,
@@ -718,11 +748,12 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
 }
 int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
-int flx_clear_queues(flx_ctx *c) { MUTATES(c); c->qs.extPend = 0; c->matQueuesEmpty = true; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+int flx_clear_queues(flx_ctx *c) { KEEP_RAW(c); MUTATES(c); c->qs.extPend = 0; c->matQueuesEmpty = true; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
     NEED(c, out32, "flx_get_counters_async: null");
+    KEEP_RAW(c);
     if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     flushExt(c);
@@ -735,6 +766,7 @@ int flx_get_counters_async(flx_ctx *c, void *out32)
 
 int flx_finish(flx_ctx *c)
 {
+    KEEP_RAW(c);
     if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -753,6 +785,7 @@ int flx_finish(flx_ctx *c)
 
 int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 {
+    KEEP_RAW(c);
     MUTATES(c);
     NEED(c, npix > 0, "flx_pixel_index_update: zero pixels");
     HIPCHK(c, hipSetDevice(c->device));
@@ -764,6 +797,7 @@ int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 }
 int flx_pixel_index_reset(flx_ctx *c)
 {
+    KEEP_RAW(c);
     MUTATES(c);
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = 0;
@@ -773,6 +807,7 @@ int flx_pixel_index_reset(flx_ctx *c)
 
 int flx_end_iteration_async(flx_ctx *c)
 {
+    KEEP_RAW(c);
     READY(c);
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend);
     c->qs.extPend = 0;
@@ -782,6 +817,7 @@ int flx_end_iteration_async(flx_ctx *c)
 }
 int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 {
+    KEEP_RAW(c);
     if (settle(c)) return 1;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out8, c->totals, 64, hipMemcpyDeviceToHost, c->stream));
@@ -792,6 +828,7 @@ int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 
 int flx_read_pixels(flx_ctx *c, int which, float *out)
 {
+    KEEP_RAW(c);                                       // framebuffers only
     MUTATES(c);
     NEED(c, c->fr.pixels && out, "flx_read_pixels: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1055,7 +1092,7 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
 }
 
 // ---- measurement
-int flx_profile_enable(flx_ctx *c, int on) { if (settle(c)) return 1; c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
+int flx_profile_enable(flx_ctx *c, int on) { KEEP_RAW(c); if (settle(c)) return 1; c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
 int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
 int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
 int flx_trace_stats_enable(flx_ctx *c, int on) { if (settle(c)) return 1; c->statsOn = on != 0; return 0; }
@@ -1155,7 +1192,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
         return 0;
     }
-    if (name && strcmp(name, "refill_extend") == 0 && value >= 0 && (value & 0xFF) <= 64 && ((value >> 8) & 0xFF) <= 64 && (value >> 17) == 0) { MUTATES(c); c->refillExt = value; return 0; }
+    if (name && strcmp(name, "refill_extend") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillExt = value; return 0; }
     if (name && strcmp(name, "refill_shadow") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillShadow = value; return 0; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }

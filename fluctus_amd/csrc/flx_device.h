@@ -153,6 +153,8 @@ __device__ __forceinline__ void wr4(float4 *p, float4 v)
 #endif
 }
 
+__device__ __forceinline__ void wr4t(float4 *p, float4 v) { *p = v; }             // temporal: re-read soon (by this thread or the next kernel)
+
 // REGENERATED PATHS WITHOUT DEAD STORES.  genRays re-initialises the whole path state (src/wf_raygen.cl:77-96): 13 records per
 // regenerated path here, 9 of them values that nothing reads before a later kernel overwrites them (the hit record until
 // traceExtension; lastBsdf / lastSpecular until the material kernel; lastEmission / lastPdfDirect / shadowRayLen until logic's NEE),

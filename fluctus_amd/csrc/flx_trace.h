@@ -80,39 +80,85 @@ __device__ __forceinline__ bool light_quad(const flx_arealight &L, f3 orig, f3 d
 // shading attributes of the winning triangle interpolated at (u, v) (src/bvh.cl:271-279; the reference re-interpolates at
 // every commit, only the last one is observable), then the implicit area-light hit (src/wf_extrays.cl:28-29,
 // src/intersect.cl:124-155), pathLen += 1 and the 12 hit columns.  Shared by the binary and the 4-wide kernels.
+// hit_values computes, commit_hit stores.
+struct HitVals { f3 P, N; float tu, tv, t; int tri, matId; uint32_t flags; };
+
+template <bool LIGHT_QUAD = true>
+__device__ __forceinline__ HitVals hit_values(const Scene &sc, const flx_render_params &p, f3 orig, f3 dir, float t, float u, float v, int tri)
+{
+    HitVals h;
+    h.P = mk3(0.0f); h.N = mk3(0.0f);
+    h.tu = 0.0f; h.tv = 0.0f;
+    h.matId = -1;
+    h.flags = 0;
+    if (tri >= 0) {
+        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
+        float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+        h.P = orig + t * dir;
+        h.N = normalize(bary(u, v, ld3(a), ld3(b), ld3(c)));
+        f3 uv = bary(u, v, mk3(a.w, b.w, 0.0f), mk3(c.w, d.x, 0.0f), mk3(d.y, d.z, 0.0f));
+        h.tu = uv.x; h.tv = uv.y;
+        h.matId = __float_as_int(d.w);
+    }
+    if (LIGHT_QUAD && p.sampleImpl && p.useAreaLight) {          // (LIGHT_QUAD false: the caller applies the quad itself, or the scene has none)
+        if (light_quad(p.areaLight, orig, dir, &t)) {
+            h.flags = 1u;
+            h.P = orig + t * dir;
+            h.N = V(p.areaLight.N);
+            tri = 0; h.matId = 0;
+        }
+    }
+    h.t = t; h.tri = tri;
+    return h;
+}
+
+// the area-light quad won (k_lightfix4 found it closer than the triangle): what hit_values' light branch sets
+__device__ __forceinline__ void hit_values_light(HitVals &h, const flx_render_params &p, f3 orig, f3 dir, float tLight)
+{
+    h.flags = 1u;
+    h.P = orig + tLight * dir;
+    h.N = V(p.areaLight.N);
+    h.tri = 0; h.matId = 0; h.t = tLight;
+}
+
+// the two bits of HITN.w: bit 0 areaLightHit comes from the commit; bit 1 backfaceHit belongs to `logic` and the reference's
+// traceExtension leaves it untouched -- except that genRays clears it: a regenerated path (pathLen still 0) must not inherit the bit of
+// the slot's previous path (flx_device.h)
+__device__ __forceinline__ uint32_t hit_keep_flags(float pathLenBits, uint32_t oldHitNw)
+{
+    const bool first = (__float_as_uint(pathLenBits) & ~FLX_FRESH) == 0u && (__float_as_uint(pathLenBits) & FLX_FRESH) != 0u;
+    return first ? 0u : (oldHitNw & 2u);
+}
+
 template <bool LIGHT_QUAD = true>
 __device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, const flx_render_params &p, uint32_t gid, f3 orig, f3 dir, float pathLenBits,
                                            float t, float u, float v, int tri, uint32_t &flags, int &matId)
 {
-    f3 P = mk3(0.0f), N = mk3(0.0f);
-    float tu = 0.0f, tv = 0.0f;
-    matId = -1;
-    flags = 0;
-    if (tri >= 0) {
-        const float4 *sp = reinterpret_cast<const float4 *>(sc.shade + tri);
-        float4 a = sp[0], b = sp[1], c = sp[2], d = sp[3];
-        P = orig + t * dir;
-        N = normalize(bary(u, v, ld3(a), ld3(b), ld3(c)));
-        f3 uv = bary(u, v, mk3(a.w, b.w, 0.0f), mk3(c.w, d.x, 0.0f), mk3(d.y, d.z, 0.0f));
-        tu = uv.x; tv = uv.y;
-        matId = __float_as_int(d.w);
-    }
-    if (LIGHT_QUAD && p.sampleImpl && p.useAreaLight) {          // (LIGHT_QUAD false: a caller that knows the scene has no area light)
-        if (light_quad(p.areaLight, orig, dir, &t)) {
-            flags = 1u;
-            P = orig + t * dir;
-            N = V(p.areaLight.N);
-            tri = 0; matId = 0;
-        }
-    }
+    const HitVals h = hit_values<LIGHT_QUAD>(sc, p, orig, dir, t, u, v, tri);
+    flags = h.flags; matId = h.matId;
     wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(pathLenBits) + 1u));          // pathLen += 1
-    wr4(st.at(S_HITP, gid), mk4(P, t));
-    // backfaceHit (bit 1) belongs to `logic`; the reference's kernel leaves it untouched
-    // (genRays clears it; a regenerated path -- pathLen still 0 -- must not inherit the bit of the slot's previous path: flx_device.h)
-    const bool first = (__float_as_uint(pathLenBits) & ~FLX_FRESH) == 0u && (__float_as_uint(pathLenBits) & FLX_FRESH) != 0u;
-    const uint32_t keep = first ? 0u : (__float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]) & 2u);
-    wr4(st.at(S_HITN, gid), mk4u(N, flags | keep));
-    wr4(st.at(S_HITUV, gid), make_float4(tu, tv, __int_as_float(tri), __int_as_float(matId)));
+    wr4(st.at(S_HITP, gid), mk4(h.P, h.t));
+    const uint32_t keep = hit_keep_flags(pathLenBits, __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]));
+    wr4(st.at(S_HITN, gid), mk4u(h.N, h.flags | keep));
+    wr4(st.at(S_HITUV, gid), make_float4(h.tu, h.tv, __int_as_float(h.tri), __int_as_float(h.matId)));
+}
+
+// RAW HIT RECORDS (round 3).  The persistent-wave closest-hit kernel (trace4r.hip) does not commit: a finished lane stores
+//     HITUV = {u, v, FLX_RAW | [FLX_RAW_LIGHT] | (triangle + 1), t}
+// and the commit happens where the record is consumed anyway -- in the fused logic pass of the next iteration (logic.hip: k_logic<FUSE, RAW>),
+// which has the ray in registers and needs the shading attributes next -- or, when anything else wants to look first (a read-back, the
+// separate kernels, the microkernels ...), in k_materialise (api.hip: settle).  A committed record holds the hit index there (>= -1), so
+// bits 31:30 == 01 marks a raw one unambiguously for scenes below 2^29 triangles.
+#define FLX_RAW       0x40000000u
+#define FLX_RAW_LIGHT 0x20000000u
+#define FLX_RAW_TRI   0x1FFFFFFFu
+__device__ __forceinline__ bool hit_is_raw(uint32_t z) { return (z & 0xC0000000u) == FLX_RAW; }
+__device__ __forceinline__ HitVals hit_values_raw(const Scene &sc, const flx_render_params &p, f3 orig, f3 dir, float4 raw)
+{
+    const uint32_t z = __float_as_uint(raw.z);
+    HitVals h = hit_values<false>(sc, p, orig, dir, raw.w, raw.x, raw.y, (int)(z & FLX_RAW_TRI) - 1);
+    if (z & FLX_RAW_LIGHT) hit_values_light(h, p, orig, dir, raw.w);
+    return h;
 }
 
 struct Stack {

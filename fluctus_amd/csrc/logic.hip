@@ -23,6 +23,7 @@
 // arithmetic.  Queue contents, counters and the extension-queue order are the ones the separate kernels produce: the
 // scatter kernel appends the material lists to the extension queue at the slots the material kernels would compute.
 #include "flx_bsdf.h"
+#include "flx_trace.h"          // hit_values_raw: the commit of traceExtension for RAW hit records
 
 namespace flxd {
 
@@ -64,7 +65,13 @@ __device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
     }
 }
 
-template <int FUSE>
+// RAW: paths may carry RAW hit records (flx_trace.h), left by the persistent-wave extension kernel (trace4r.hip).  The pass then does the
+// commit of traceExtension itself, in registers -- shading-record gather, normal / uv interpolation, pathLen + 1 -- right where it would
+// have loaded the committed record, and stores what the committed state holds (hit point and uv record of the continuing paths; the normal
+// record is written here anyway).  Only used when genRays follows in the same fused chain: a path that terminates is regenerated there, and
+// a regenerated path's hit record is dead (flx_device.h: REGENERATED PATHS), so nothing of it has to be stored but the record's raw marker
+// cleared.
+template <int FUSE, bool RAW = false>
 __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, uint32_t firstIteration)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
@@ -80,7 +87,6 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         const float4 huv = rd4(st.at(S_HITUV, gid));
         const float4 ei4 = rd4(st.at(S_EI, gid));
         uint32_t seed = __float_as_uint(thr.w);
-        const uint32_t len = __float_as_uint(d4.w) & ~FLX_FRESH;           // flag bits of a regenerated path: flx_device.h
         const uint32_t pixIdx = __float_as_uint(ei4.w) & ~FLX_FRESH;
         float eiw = ei4.w;                                                  // pixel index + "no NEE sample since regeneration"
         const f3 rayOrig = ld3(o4), rayDir = ld3(d4);
@@ -88,9 +94,19 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         f3 T = ld3(thr);
         f3 Ei = ld3(ei4);
         f3 hitN = ld3(hn);
-        const uint32_t hflags = __float_as_uint(hn.w);
-        const int hitI = __float_as_int(huv.z), hitMat = __float_as_int(huv.w);
-        const f2 hitUV = mk2(huv.x, huv.y);
+        uint32_t hflags = __float_as_uint(hn.w);
+        int hitI = __float_as_int(huv.z), hitMat = __float_as_int(huv.w);
+        f2 hitUV = mk2(huv.x, huv.y);
+        uint32_t lenBits = __float_as_uint(d4.w);
+        bool isRaw = false; f3 rawP = mk3(0.0f); float rawT = 0.0f;
+        if (RAW && hit_is_raw(__float_as_uint(huv.z))) {                    // the commit of traceExtension (flx_trace.h: RAW HIT RECORDS)
+            isRaw = true;
+            const HitVals h = hit_values_raw(sc, p, rayOrig, rayDir, huv);
+            hflags = h.flags | hit_keep_flags(d4.w, hflags);
+            hitN = h.N; hitI = h.tri; hitMat = h.matId; hitUV = mk2(h.tu, h.tv); rawP = h.P; rawT = h.t;
+            lenBits += 1u;                                                  // pathLen += 1
+        }
+        const uint32_t len = lenBits & ~FLX_FRESH;                         // flag bits of a regenerated path: flx_device.h
         bool Tdirty = false;
 
         // russian roulette (src/wf_logic.cl:60-69)
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         } else if (p.useAreaLight && (hflags & 1u) && !terminate) {   // implicit area-light sample, :111-131
             float misWeight = 1.0f;
             const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
-            const f3 hitP = ld3(rd4(st.at(S_HITP, gid)));
+            const f3 hitP = (RAW && isRaw) ? rawP : ld3(rd4(st.at(S_HITP, gid)));
             if (p.sampleExpl && len > 1u && !lastSpecular) {
                 float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
                 float directPdfW = pdf_a_to_w(directPdfA, length(hitP - rayOrig), dot(normalize(-rayDir), hitN));
@@ -151,13 +167,23 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             }
             wr4(st.at(S_EI, gid), mk4(Ei, ei4.w));
             wr4(st.at(S_THR, gid), mk4u(T, seed));
+            if (RAW && isRaw) wr4(st.at(S_HITUV, gid), make_float4(hitUV.x, hitUV.y, __int_as_float(hitI), __int_as_float(hitMat)));      // (clears the raw marker)
             member = 1u;
         } else {
             const flx_material mat = sc.materials[hitMat];            // :180-184
             hitN = tangent_space_normal(sc, hitN, hitUV, hitI, mat.map_N);
             const bool backface = dot(hitN, rayDir) > 0.0f;
             if (backface) hitN = hitN * -1.0f;
-            const f3 hitP = ld3(rd4(st.at(S_HITP, gid)));
+            const f3 hitP = (RAW && isRaw) ? rawP : ld3(rd4(st.at(S_HITP, gid)));
+            if (RAW && isRaw) {                                       // the committed hit record: point and uv here, the normal below
+                if (FUSE == USE_ALL) {                                // (re-read at the material step below: keep the lines)
+                    wr4t(st.at(S_HITP, gid), mk4(rawP, rawT));
+                    wr4t(st.at(S_HITUV, gid), make_float4(hitUV.x, hitUV.y, __int_as_float(hitI), __int_as_float(hitMat)));
+                } else {
+                    wr4(st.at(S_HITP, gid), mk4(rawP, rawT));
+                    wr4(st.at(S_HITUV, gid), make_float4(hitUV.x, hitUV.y, __int_as_float(hitI), __int_as_float(hitMat)));
+                }
+            }
             const f3 orig = hitP - 1e-3f * rayDir;
             if (fr.aovNormal) {                                       // denoiser features, :186-209
                 if (len == 1u) {
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                 // evaluate toward it regardless, src/wf_mat_diffuse.cl:34-37; logic consumes the result only behind an unblocked ray)
                 const f3 L = haveL ? Lnee : ld3(rd4(st.at(S_SHD, gid)));
                 MatStep o;
-                if (FUSE == USE_ALL) {
+                if (FUSE == USE_ALL) {          // (a RAW path stored its hit point and uv record above: same thread, same addresses, program order)
                     // the all-types kernel is register-bound (106 VGPRs, 4 waves/SIMD): re-reading the hit point, uv, material and ray
                     // direction here (L1/L2-hot, this thread loaded them above) instead of keeping them live across the NEE code brings
                     // it to 87 VGPRs and 5 waves (-3 % kernel time); the diffuse-only kernel stays at 5 waves either way
@@ -250,6 +276,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
                 wr4(st.at(S_DIR, gid), mk4u(o.newDir, len));               // pathLen without the FLX_FRESH flag, as the material kernels leave it
             } else {
                 wr4(st.at(S_THR, gid), mk4u(T, seed));
+                if (RAW && isRaw) wr4(st.at(S_DIR, gid), mk4u(rayDir, lenBits));      // pathLen + 1 for the material kernel that serves this path
             }
         }
     }
@@ -389,15 +416,21 @@ uint32_t fused_queue_mask(int fuse)
 
 // fuse: 0 = the plain logic kernel | USE_DIFFUSE | USE_ALL  (diffuse + glossy was measured too: never the best of the three)
 void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
-                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId)
+                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId, int raw)
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
     LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks)};
     const dim3 g(blocks), b(LOGIC_BLOCK);
     switch (fuse) {
-    case USE_DIFFUSE: hipLaunchKernelGGL(k_logic<USE_DIFFUSE>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
-    case USE_ALL: hipLaunchKernelGGL(k_logic<USE_ALL>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
+    case USE_DIFFUSE:
+        if (raw) hipLaunchKernelGGL((k_logic<USE_DIFFUSE, true>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        else hipLaunchKernelGGL((k_logic<USE_DIFFUSE, false>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        break;
+    case USE_ALL:
+        if (raw) hipLaunchKernelGGL((k_logic<USE_ALL, true>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        else hipLaunchKernelGGL((k_logic<USE_ALL, false>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        break;
     default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
     }
     hipLaunchKernelGGL(k_queue_scan, dim3(NUM_LISTS), dim3(1024), 0, s, aux, qs.counters);

@@ -1,22 +1,30 @@
 // trace4r.hip -- closest-hit and any-hit traversal of the 4-wide tree with PERSISTENT WAVES AND LANE REFILL (round 3).
 //
-// Why.  k_extend4 / k_shadow4 (trace4.hip) are VALU-issue-bound: 5.3e8 VALU wave-instructions per 4 M-ray launch at the ~4 SIMD-cycles
-// every plain VALU instruction costs on gfx950 (scripts/ubench/valu_rate.hip) IS the kernel time (0.85 ms), and only 26 % of the lanes of
-// those instructions do work -- a thread-per-ray wave lives as long as its longest ray (~25 node visits against a mean of 10.5) and,
-// inside it, the descent loop runs as long as its longest descent.  Here a wave keeps its lanes busy: the grid is the number of waves
-// the machine holds at once, wave w works through the 64-ray blocks w, w + G, w + 2G, ... of the queue (no atomics: a hot counter
-// sustains only ~88 atomics/us), and whenever at least `refillMin` lanes have finished their ray, those lanes write their result and
-// take the next rays of the wave's block.
+// Why.  k_extend4 / k_shadow4 (trace4.hip) are VALU-issue-bound: 5.0e8 VALU wave-instructions per 4 M-ray launch at the ~4 SIMD-cycles most
+// VALU instructions cost on gfx950 (scripts/ubench/valu_pairs*.hip: everything but mov / mul / add / logic ops issues on ONE of the SIMD's two
+// pipes) IS the kernel time (0.85 ms), and only 26 % of the lanes of those instructions do work: a thread-per-ray wave lives as long as its
+// longest ray (~25 node visits against a mean of 10.5) and, inside it, every descent round lasts as long as its longest descent.  Here
+//   * the grid is the number of waves the machine holds at once; wave w works through the 64-ray blocks w, w + G, w + 2G, ... of the queue
+//     (no atomics: a hot counter sustains only ~88 atomics/us) and hands the next rays of its block to lanes that have finished as soon as
+//     `refillMin` of them are idle;
+//   * a descent round ends when `waitMax` lanes stand on a leaf instead of when the last lane does (the lanes still descending simply go on
+//     in the next round).
+// Measured (kitchen, 4 M rays, refillMin 16, waitMax 32): VALU instructions 5.0e8 -> 2.8e8, lanes per instruction 16.7 -> 29.7, kernel time
+// 0.844 -> 0.604 ms.  Refill alone (waitMax 64): 4.1e8 instructions, 0.754 ms.
 //
-// Round 2 tried this (scripts/experiments/trace4p.hip.txt) and lost: 100 VGPRs -> 4 waves per SIMD, and the full commit of
-// traceExtension (shading-record gather, normalisation, light quad: ~150 instructions + 4 loads) ran at every refill for a handful of
-// lanes.  Differences here: (1) the closest-hit kernel does NOT commit -- a finished lane stores its raw result {u, v, triangle, t} in
-// the path's HITUV record (one 16-byte store) and k_commit4, a streaming kernel over the same queue, turns it into the hit record
-// afterwards (it runs beside the shadow traversal, which is VALU-bound while this one is memory-bound); (2) nothing of the commit is
-// live in the loop, so the kernel keeps the register budget of k_extend4.
+// The commit.  Round 2 tried persistent waves with the full commit of traceExtension at the refill and lost (100 VGPRs, and the commit's
+// instruction stream and memory round trips ran for a handful of lanes at a time); round 3 measured three more placements (archived in
+// scripts/experiments/trace4r_commit_variants.hip.txt): by the finishing lanes at the refill without the light quad (72 VGPRs, but
+// 0.60 -> 0.85 ms), parked in LDS and committed 64 at a time in completion order (0.90 ms) or in queue order (1.02 ms: too many partial
+// flushes), and as a separate streaming pass over the queue (0.60 + 0.21 ms).  Every one costs more than it saves, because the commit is pure
+// memory work (200 B per ray, three dependent round trips) that the thread-per-ray kernel hides under its VALU-bound waves and a
+// latency-bound persistent kernel cannot.  So the kernel does not commit at all: a finished lane stores the RAW result
+// {u, v, triangle, t} in the path's HITUV record (one 16-byte store) and the commit happens where the record is consumed anyway -- inside the
+// next fused logic pass (logic.hip: k_logic<FUSE, RAW>: it has the ray in registers and needs the shading record next) -- or, if anything else
+// looks first, in k_materialise (flx_trace.h: RAW HIT RECORDS; api.hip: settle).
 //
-// Per-ray arithmetic is exactly that of k_extend4 / k_shadow4 (same wide_node_visit / wide_leaf_visit, the ray's own stack column), so
-// the results are bit-identical to those kernels whatever lane or wave a ray lands on (tests/test_gpu_wide.py).
+// Per-ray arithmetic is exactly that of k_extend4 / k_shadow4 (same wide_node_visit / wide_leaf_visit, the ray's own stack column), so the
+// results are bit-identical to those kernels whatever lane or wave a ray lands on (tests/test_gpu_wide.py).
 // Replaces reference kernels traceExtension (src/wf_extrays.cl:5-36) and traceShadow (src/wf_shadowrays.cl:6-38).
 #include "flx_trace4.h"
 
@@ -27,9 +35,7 @@ namespace flxd {
 #endif
 #define R_NONE 0xFFFFFFFFu
 
-__device__ __noinline__ bool light_quad_call(const flx_arealight &L, f3 orig, f3 dir, float *t) { return light_quad(L, orig, dir, t); }
-
-template <bool ANY_HIT, bool LIGHT, int ANY_ORDER, bool INLINE_COMMIT = false>
+template <bool ANY_HIT, int ANY_ORDER>
 __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
     float tbest = 0.0f, ubest = 0.0f, vbest = 0.0f;
     int tribest = -1;
     bool occluded = false;
-    uint32_t nI = 0, nT = 0;                         // (visit counters of the shared helpers; unused without STATS)
+    uint32_t nT = 0;                                 // (visit counter of the shared leaf helper; unused without STATS)
 
     for (;;) {
         const bool idle = cur == FLX_RAY_DONE;
@@ -61,20 +67,8 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
         const uint32_t nIdle = (uint32_t)__popcll(idleMask);
         if ((int)nIdle >= refillMin || nIdle == 64u) {                   // wave-uniform
             if (idle && gid != R_NONE) {
-                if (ANY_HIT) {
-                    // the light quad blocks too (src/wf_shadowrays.cl:32-33 tests it first; the result is the OR either way).  Tested here,
-                    // for the rays the tree did not block, so that nothing of it is live while the tree is walked.
-                    if (LIGHT && !occluded) { float tl = tbest; occluded = light_quad_call(p.areaLight, r.orig, r.dir, &tl); }
-                    st.blocked[gid] = occluded ? 1u : 0u;
-                }
-                else if (INLINE_COMMIT) {
-                    // the full commit of traceExtension, here and now, for the lanes that finished (pathLen is re-read: nothing of the
-                    // commit stays live while the tree is walked)
-                    uint32_t flags; int matId;
-                    const float plen = reinterpret_cast<const float *>(st.at(S_DIR, gid))[3];
-                    commit_hit<LIGHT>(st, sc, p, gid, r.orig, r.dir, plen, tbest, ubest, vbest, tribest, flags, matId);
-                }
-                else wr4(st.at(S_HITUV, gid), make_float4(ubest, vbest, __int_as_float(tribest), tbest));      // raw result -> k_commit4
+                if (ANY_HIT) st.blocked[gid] = occluded ? 1u : 0u;
+                else wr4(st.at(S_HITUV, gid), make_float4(ubest, vbest, __uint_as_float(FLX_RAW | (uint32_t)(tribest + 1)), tbest));      // flx_trace.h: RAW HIT RECORDS
                 gid = R_NONE;
             }
             if (blk < nblk) {
@@ -112,20 +106,52 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
             else cur = stk.pop(sp);
         }
     }
-    (void)nI;
 }
 
-// The commit of traceExtension for every ray of the extension queue, from the raw result k_trace4r left in HITUV (flx_trace.h: commit_hit).
-__global__ __launch_bounds__(256) void k_commit4(State st, Queues qs, Scene sc, flx_render_params p)
+// The commit of traceExtension for every path whose hit record is still raw (flx_trace.h: RAW HIT RECORDS): what k_logic<FUSE, RAW> does in
+// registers, done in memory for whoever wants to look first.  Runs over all paths (a raw record says so itself).
+__global__ __launch_bounds__(256) void k_materialise(State st, Scene sc, flx_render_params p)
 {
-    const uint32_t qlen = ext_len(qs);
-    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < qlen; idx += gridDim.x * blockDim.x) {
-        const uint32_t gid = qs.q[FLX_Q_EXTENSION][idx];
+    for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < st.numTasks; gid += gridDim.x * blockDim.x) {
         const float4 raw = rd4t(st.at(S_HITUV, gid));
+        if (!hit_is_raw(__float_as_uint(raw.z))) continue;
         const float4 o4 = rd4(st.at(S_ORIG, gid));
         const float4 d4 = rd4(st.at(S_DIR, gid));
-        uint32_t flags; int matId;
-        commit_hit(st, sc, p, gid, ld3(o4), ld3(d4), d4.w, raw.w, raw.x, raw.y, __float_as_int(raw.z), flags, matId);
+        const f3 orig = ld3(o4), dir = ld3(d4);
+        const HitVals h = hit_values_raw(sc, p, orig, dir, raw);
+        wr4(st.at(S_DIR, gid), mk4u(dir, __float_as_uint(d4.w) + 1u));            // pathLen += 1
+        wr4(st.at(S_HITP, gid), mk4(h.P, h.t));
+        const uint32_t keep = hit_keep_flags(d4.w, __float_as_uint(reinterpret_cast<const float *>(st.at(S_HITN, gid))[3]));
+        wr4(st.at(S_HITN, gid), mk4u(h.N, h.flags | keep));
+        wr4(st.at(S_HITUV, gid), make_float4(h.tu, h.tv, __int_as_float(h.tri), __int_as_float(h.matId)));
+    }
+}
+
+// The area-light quad, applied AFTER the traversal for scenes that have one (two more triangle tests with their corner set-up: inlined in
+// k_trace4r they cost 30 VGPRs = three waves per SIMD; as a streaming pass they cost ~50 B per ray).
+//  closest hit (src/wf_extrays.cl:28-29, src/intersect.cl:124-155): the quad wins when it is not farther than the triangle found: the raw
+//    record gets the quad's t and FLX_RAW_LIGHT, and whoever commits it (hit_values_raw) applies what commit_hit's light branch does;
+//  any hit (src/wf_shadowrays.cl:32-33): the quad blocks like any triangle; the reference tests it first, the result is the OR either way.
+template <bool ANY_HIT>
+__global__ __launch_bounds__(256) void k_lightfix4(State st, Queues qs, flx_render_params p)
+{
+    const uint32_t qlen = ANY_HIT ? qs.counters[FLX_Q_SHADOW] : ext_len(qs);
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < qlen; idx += gridDim.x * blockDim.x) {
+        const uint32_t gid = qs.q[ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION][idx];
+        if (ANY_HIT) {
+            if (st.blocked[gid]) continue;
+            const float4 o4 = rd4(st.at(S_SHO, gid)), d4 = rd4(st.at(S_SHD, gid));
+            float tl = o4.w;                                             // shadowRayLen
+            if (light_quad(p.areaLight, ld3(o4), ld3(d4), &tl)) st.blocked[gid] = 1u;
+        } else {
+            const float4 o4 = rd4(st.at(S_ORIG, gid)), d4 = rd4(st.at(S_DIR, gid));
+            float4 raw = rd4t(st.at(S_HITUV, gid));
+            float t = raw.w;
+            if (light_quad(p.areaLight, ld3(o4), ld3(d4), &t)) {
+                raw.w = t; raw.z = __uint_as_float(__float_as_uint(raw.z) | FLX_RAW_LIGHT);
+                wr4(st.at(S_HITUV, gid), raw);
+            }
+        }
     }
 }
 
@@ -143,41 +169,36 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
     return g < blocks ? g : blocks;
 }
 
+// refill = refillMin | waitMax << 8.  Leaves RAW hit records behind (the caller remembers: api.hip, flx_ctx::rawHits).
 void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill)
 {
-    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;          // option value: refillMin | waitMax << 8
-    static int occ[2] = {0, 0};
+    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
+    static int occ = 0;
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
-    // The commit: inline at the refill where it is cheap in registers -- without the implicit area-light quad (two more triangle tests with
-    // their corner set-up) it fits the 72 VGPRs of 7 waves per SIMD; with it the kernel needs 102 -> 4 waves, so scenes with an area light
-    // take the separate pass.  Bit 16 of the option forces the separate pass (A/B).
-    const bool lightQuad = p.sampleImpl && p.useAreaLight;
-    if (!lightQuad && !(refill & 0x10000)) {
-        const uint32_t grid = persistent_grid(k_trace4r<false, false, 0, true>, occ[1], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<false, false, 0, true>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
-        return;
-    }
-    const uint32_t grid = persistent_grid(k_trace4r<false, false, 0>, occ[0], numCUs, st.numTasks);
-    hipLaunchKernelGGL((k_trace4r<false, false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
-    hipLaunchKernelGGL(k_commit4, dim3(numCUs * 8), dim3(256), 0, s, st, qs, sc, p);
+    const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks);
+    hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+    if (p.sampleImpl && p.useAreaLight) hipLaunchKernelGGL(k_lightfix4<false>, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
+}
+
+void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t numCUs)
+{
+    hipLaunchKernelGGL(k_materialise, dim3(numCUs * 8), dim3(256), 0, s, st, sc, p);
 }
 
 void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill)
 {
-    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;          // option value: refillMin | waitMax << 8
-    static int occ[3] = {0, 0, 0};
+    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
+    static int occ[2] = {0, 0};
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
-    const bool farFirst = p.useEnvMap && !p.useAreaLight;            // visit order of the any-hit traversal (trace4.hip: launch_shadow4)
-    if (p.useAreaLight) {
-        const uint32_t grid = persistent_grid(k_trace4r<true, true, 0>, occ[0], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<true, true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
-    } else if (farFirst) {
-        const uint32_t grid = persistent_grid(k_trace4r<true, false, 1>, occ[1], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<true, false, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+    // visit order of the any-hit traversal (trace4.hip: launch_shadow4): far -> near when every shadow ray runs toward the environment light
+    if (p.useEnvMap && !p.useAreaLight) {
+        const uint32_t grid = persistent_grid(k_trace4r<true, 1>, occ[1], numCUs, st.numTasks);
+        hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
     } else {
-        const uint32_t grid = persistent_grid(k_trace4r<true, false, 0>, occ[2], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<true, false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+        const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks);
+        hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
     }
+    if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4<true>, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
 }
 
 } // namespace flxd

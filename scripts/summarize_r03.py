@@ -1,0 +1,66 @@
+"""Summarise a scripts/profile_r03.sh capture into profiles/r03_<workload>_{kernel_stats.csv,counters.txt} and profiles/traffic_<workload>.json
+(the file bench.py reads for roofline.traffic / frac)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, wl, extra = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prof = os.path.join(root, "profiles")
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(prof, f"r03_{wl}_kernel_stats.csv"))
+KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
+        "k_queue_scatter", "k_queue_scan")
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        for key in KEYS:
+            if key in k:
+                a = acc[key][r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"]); a[1] += 1
+                break
+lines = []
+traffic = {}
+for k in sorted(acc):
+    v = {c: a[0] / a[1] for c, a in acc[k].items()}
+    lines.append(f"== {k}   (averages per dispatch, {max(a[1] for a in acc[k].values())} dispatches)")
+    for c in sorted(v):
+        lines.append("   %-28s %.6g" % (c, v[c]))
+    rd, r32, r64, r128 = (v.get("TCC_EA0_RDREQ_sum", 0), v.get("TCC_EA0_RDREQ_32B_sum", 0), v.get("TCC_EA0_RDREQ_64B_sum", 0), v.get("TCC_EA0_RDREQ_128B_sum", 0))
+    wr, w64 = v.get("TCC_EA0_WRREQ_sum", 0), v.get("TCC_EA0_WRREQ_64B_sum", 0)
+    if rd or wr:
+        rbytes = 32 * r32 + 64 * r64 + 128 * r128 + 64 * max(0.0, rd - r32 - r64 - r128)
+        wbytes = 64 * w64 + 32 * (wr - w64)
+        lines.append("   fabric read bytes %.6g (requests: 32 B %g, 64 B %g, 128 B %g)   write bytes %.6g   total %.6g" % (rbytes, r32, r64, r128, wbytes, rbytes + wbytes))
+        if "FETCH_SIZE" in v:
+            lines.append("   cross-check: 2 x FETCH_SIZE + WRITE_SIZE = %.6g bytes (KiB counters; gfx950: FETCH_SIZE tallies 128-B requests at 64 B)" % (2 * v["FETCH_SIZE"] * 1024 + v.get("WRITE_SIZE", 0) * 1024))
+        traffic[k] = {"read_bytes": rbytes, "write_bytes": wbytes, "read_requests_128B": r128, "read_requests_64B": r64, "read_requests_32B": r32,
+                      "write_requests_64B": w64, "write_requests_32B": wr - w64, "fetch_size_kib": v.get("FETCH_SIZE"), "write_size_kib": v.get("WRITE_SIZE")}
+    if v.get("SQ_INSTS_VALU"):
+        lines.append("   lanes active per VALU instruction %.1f of 64" % (v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]))
+open(os.path.join(prof, f"r03_{wl}_counters.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(prof, f"r03_{wl}_bench.json")).readline())
+except Exception:
+    pass
+ext = next((k for k in ("k_trace4r<false", "k_extend4<false>", "k_extend<false>") if k in traffic), None)
+if ext:
+    cfg = bench.get("config", {})
+    t = traffic[ext]
+    extra_k = {k: traffic[k]["read_bytes"] + traffic[k]["write_bytes"] for k in ("k_commit4", "k_lightfix4") if k in traffic}
+    j = {"source": f"scripts/profile_r03.sh {wl} {extra}".strip() + " -> profiles/r03_%s_counters.txt (rocprofv3 --pmc, separate passes with --kernel-trace only)" % wl,
+         "kernel": ext, "workload": wl, "extend_tree": 4 if "4" in ext else 2, "num_tasks": cfg.get("num_tasks_per_gpu"), "refill_extend": cfg.get("refill_extend", 0),
+         "extend_read_requests_128B": t["read_requests_128B"], "extend_read_requests_64B": t["read_requests_64B"], "extend_write_requests_64B": t["write_requests_64B"],
+         "extend_write_requests_32B": t["write_requests_32B"], "fetch_size_kib": t["fetch_size_kib"], "write_size_kib": t["write_size_kib"],
+         "companion_kernels_bytes": extra_k,
+         "correction": "gfx950 guide: FETCH_SIZE = TCC_EA0_RDREQ x 64 B although the requests are 128 B -> read bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B; write bytes = 64 x WRREQ_64B + 32 x the rest.  Fabric-side counts: Infinity-Cache hits are included, HBM proper is lower.",
+         "extend_hbm_bytes_per_launch": t["read_bytes"] + t["write_bytes"] + sum(extra_k.values())}
+    json.dump(j, open(os.path.join(prof, f"traffic_{wl}.json"), "w"), indent=1)
+    print("wrote traffic_%s.json: %.4g bytes per launch" % (wl, j["extend_hbm_bytes_per_launch"]))

@@ -309,11 +309,15 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
-@pytest.mark.parametrize("workload,refill", [("kitchen", 16), ("conference", 8 | (16 << 8)), ("kitchen", 48 | (8 << 8)), ("courtyard-1440p", 16 | (24 << 8))])
+# refill option = refillMin | waitMax << 8 (trace4r.hip)
+@pytest.mark.parametrize("workload,refill", [("kitchen", 16 | (32 << 8)), ("conference", 8 | (16 << 8)), ("kitchen", 48 | (8 << 8)), ("kitchen", 16),
+                                             ("courtyard-1440p", 16 | (24 << 8))])
 def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
     """Persistent waves with lane refill (trace4r.hip) run the SAME per-ray code as k_extend4 / k_shadow4, whatever lane or wave a ray
-    lands on and whenever it is handed out: two contexts free-run the workload at 1 M paths, one with the thread-per-ray kernels, one with
-    the refill kernels (+ k_commit4); counters after every iteration, the final path state and every queue are identical, the
+    lands on and whenever it is handed out, and the commit of traceExtension -- done by the next fused logic pass from the RAW hit records
+    (logic.hip: k_logic<FUSE, RAW>), or by k_materialise when the state is read first -- is the same arithmetic as commit_hit's: two contexts
+    free-run the workload at 1 M paths, one with the thread-per-ray kernels, one with the refill kernels; counters after every iteration,
+    the path state after iterations 3 and 12 (the first export commits raw records in memory, the run continues from there) and the
     framebuffers within the atomic-order bound."""
     from fluctus_amd.device import HipContext
     import bench
@@ -330,6 +334,9 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
     for it in range(12):
         ca, cb = driver.benchmark_iteration(a, npix), driver.benchmark_iteration(b, npix)
         assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
+        if it == 2:
+            fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+            assert not fails, "after 3 iterations: " + "; ".join(fails[:5])
     fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
     assert not fails, "; ".join(fails[:5])
     assert common.fb_close(a.read_pixels(0), b.read_pixels(0))
