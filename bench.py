@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--xcd-remap", type=int, default=0)
     ap.add_argument("--extend-tree", type=int, default=4, choices=(2, 4), help="tree flx_wf_extend walks: 4-wide quantised (default) or the reference's binary tree (bit-exact)")
     ap.add_argument("--shadow-tree", type=int, default=4, choices=(2, 4))
-    ap.add_argument("--overlap", type=int, default=2)
+    ap.add_argument("--overlap", type=int, default=-1, help="stream schedule of the two traversals: 0 serial, 1 shadow beside extension, 2 shadow right after logic, -1 = what flx_upload_scene picks for the scene")
     ap.add_argument("--fuse", type=int, default=1, choices=(0, 1), help="logic + material kernels as one fused pass (default) or the separate kernels")
     ap.add_argument("--ext-order", type=int, default=-1, choices=(-1, 0, 1), help="fused pass: extension queue lists the continuing paths by path id (1) or in one segment per material queue (0); -1 = what flx_upload_scene chose")
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
@@ -492,7 +492,7 @@ def main():
                                     "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
                        "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
-                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"),
+                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},

@@ -56,7 +56,8 @@ struct flx_ctx {
     hipEvent_t evPreExt = nullptr, evShadow = nullptr, evPostLogic = nullptr;
     bool overlapOK = false;                     // true between flx_wf_extend and the next enqueue
     bool logicChain = false, logicChainPrev = false;   // only raygen / materials / extend enqueued since flx_wf_logic
-    int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic
+    int overlap = 1;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
+    int overlapOpt = -1;                        // option "overlap": -1 = chosen per scene at flx_upload_scene (pickSchedule), else as set
     uint32_t *spill2 = nullptr;
     // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
     // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
@@ -92,7 +93,9 @@ struct flx_ctx {
     // visit-order ties
     int shadowTree = 4, extendTree = 4;
     // persistent waves with lane refill for the 4-wide kernels (trace4r.hip): 0 = thread-per-ray kernels, n > 0 = refill when n lanes are idle
-    int refillExt = 0, refillShadow = 0;
+    // (closest hit: on by default -- refillMin 16, waitMax 32: kitchen 0.82 -> 0.61 ms per 4 M rays; any hit: per scene, pickSchedule)
+    int refillExt = 16 | (32 << 8), refillShadow = 0;
+    int refillShadowOpt = -1;                   // option "refill_shadow": -1 = per scene, else as set
     // The persistent-wave extension kernel leaves RAW hit records (flx_trace.h): true from flx_wf_extend until they are committed -- by the
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as any other entry point runs (settle; the calls of the steady-state loop set keepRaw first).
@@ -218,7 +221,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     c->device = device; c->numTasks = num_tasks;
     // A/B hooks for whole test-suite runs: the defaults of the refill_extend / refill_shadow options
     if (const char *e = getenv("FLX_REFILL_EXTEND")) c->refillExt = atoi(e);
-    if (const char *e = getenv("FLX_REFILL_SHADOW")) c->refillShadow = atoi(e);
+    if (const char *e = getenv("FLX_REFILL_SHADOW")) { c->refillShadowOpt = atoi(e); c->refillShadow = c->refillShadowOpt < 0 ? 0 : c->refillShadowOpt; }
     auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     // (stream priorities were tried: a high-priority shadow stream keeps the extension kernel at its undisturbed 0.86 ms and inflates
@@ -315,6 +318,23 @@ int flx_destroy(flx_ctx *c)
 uint32_t flx_num_tasks(flx_ctx *c) { return c->numTasks; }
 // (an interop caller enqueues its own work behind ours on this stream: a deferred flx_wf_logic / flx_wf_raygen must be in it by then)
 void *flx_stream(flx_ctx *c) { (void)settle(c); return (void *)c->stream; }
+
+// How the two traversals share the machine, chosen per scene unless the options say otherwise (the reference specialises per scene too:
+// it recompiles its kernels with -DBXDF_USE_* at every scene load).  Measured with the persistent-wave extension kernel (one box, Mrays/s):
+//                          shadow || extension    shadow right after logic    serial, any-hit kernel persistent too
+//   kitchen    (35 MB tree)        5421                    5366                        5131
+//   conference (16 MB)             5085                    4848                        4598
+//   courtyard  (0.6 GB)            1896                    1850 (1903 both persistent) 1963
+// A tree that lives in L2 / Infinity Cache: the thread-per-ray shadow kernel fills the tail of the persistent extension kernel (schedule 1).
+// A tree that comes from HBM: both traversals wait for the same misses, co-scheduling buys nothing and the persistent any-hit kernel's
+// fewer instructions do (schedule 0 + refill_shadow).
+static void pickSchedule(flx_ctx *c)
+{
+    const size_t treeBytes = (size_t)c->wideInfo[0] * 64 + (size_t)c->wideInfo[1] * 16;
+    const bool hbmTree = treeBytes > ((size_t)192 << 20);          // well beyond what the 256 MB Infinity Cache keeps beside 0.8 GB of streamed path state
+    c->overlap = c->overlapOpt >= 0 ? c->overlapOpt : (hbmTree ? 0 : 1);
+    c->refillShadow = c->refillShadowOpt >= 0 ? c->refillShadowOpt : (hbmTree ? (16 | (32 << 8)) : 0);
+}
 
 // ---- scene upload: reference wire arrays -> traversal layout -------------------------------
 int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t *indices, size_t nidx,
@@ -508,6 +528,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     c->wideOK = wide.nested;
     c->wideInfo[0] = (uint32_t)wide.nodes.size(); c->wideInfo[1] = (uint32_t)(wide.leafdata.size()); c->wideInfo[2] = wide.maxStack; c->wideInfo[3] = wide.nested ? 1u : 0u;
     c->wideInfo[4] = binDepth; c->wideInfo[5] = spillLevels; c->wideInfo[6] = (uint32_t)bnodes.size(); c->wideInfo[7] = wide.maxLeafCount;
+    pickSchedule(c);
     return 0;
 }
 
@@ -1184,7 +1205,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
     if (name && strcmp(name, "ext_order") == 0 && (value == 0 || value == 1)) { c->extOrder = value; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
-    if (name && strcmp(name, "overlap") == 0 && value >= 0 && value <= 2) { MUTATES(c); c->overlap = value; return 0; }
+    if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { MUTATES(c); c->overlapOpt = value; pickSchedule(c); return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->shadowTree = value; return 0; }
     if (name && strcmp(name, "extend_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->extendTree = value; return 0; }
     if (name && strcmp(name, "denoiser") == 0 && (value == 0 || value == 1)) {
@@ -1193,7 +1214,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
         return 0;
     }
     if (name && strcmp(name, "refill_extend") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillExt = value; return 0; }
-    if (name && strcmp(name, "refill_shadow") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillShadow = value; return 0; }
+    if (name && strcmp(name, "refill_shadow") == 0 && value >= -1 && (value < 0 || ((value & 0xFF) <= 64 && (value >> 8) <= 64))) { MUTATES(c); c->refillShadowOpt = value; pickSchedule(c); return 0; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");

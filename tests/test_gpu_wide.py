@@ -250,7 +250,10 @@ def _free_run_default_vs_oracle(workload, n, iterations, start_iterations=0):
     d, p, env = bench.build_workload(name=workload)
     npix = int(p["width"]) * int(p["height"])
     g, o = _ctxs(d, p, n, env=env)
-    assert g.get_option("extend_tree") == 4 and g.get_option("shadow_tree") == 4 and g.get_option("fuse") == 1 and g.get_option("overlap") == 2
+    # the shipped defaults: both traversals on the 4-wide tree, persistent-wave extension kernel with RAW hit records, fused logic pass,
+    # the stream schedule flx_upload_scene picked for the scene
+    assert g.get_option("extend_tree") == 4 and g.get_option("shadow_tree") == 4 and g.get_option("fuse") == 1
+    assert g.get_option("refill_extend") > 0 and g.get_option("overlap") in (0, 1)
     for it in range(start_iterations):                  # device alone (cheap), then the oracle takes the state over ...
         cnt = driver.benchmark_iteration(g, npix)
         o.pixel_index_update(npix, int(cnt[Q.RAYGEN]))   # ... the pixel cursor included (replayed: it is host-side state of both)
@@ -326,7 +329,7 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
     ctx = []
     for r in (0, refill):
         g = HipContext(n)
-        g.set_option("refill_extend", r); g.set_option("refill_shadow", r)
+        g.set_option("refill_extend", r); g.set_option("refill_shadow", r)          # (0 = the thread-per-ray kernels: the defaults are not 0)
         g.upload_scene(d); g.upload_envmap(env); g.set_params(p); driver.reset_renderer(g)
         ctx.append(g)
     a, b = ctx
