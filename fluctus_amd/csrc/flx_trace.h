@@ -112,15 +112,6 @@ __device__ __forceinline__ HitVals hit_values(const Scene &sc, const flx_render_
     return h;
 }
 
-// the area-light quad won (k_lightfix4 found it closer than the triangle): what hit_values' light branch sets
-__device__ __forceinline__ void hit_values_light(HitVals &h, const flx_render_params &p, f3 orig, f3 dir, float tLight)
-{
-    h.flags = 1u;
-    h.P = orig + tLight * dir;
-    h.N = V(p.areaLight.N);
-    h.tri = 0; h.matId = 0; h.t = tLight;
-}
-
 // the two bits of HITN.w: bit 0 areaLightHit comes from the commit; bit 1 backfaceHit belongs to `logic` and the reference's
 // traceExtension leaves it untouched -- except that genRays clears it: a regenerated path (pathLen still 0) must not inherit the bit of
 // the slot's previous path (flx_device.h)
@@ -144,21 +135,17 @@ __device__ __forceinline__ void commit_hit(const State &st, const Scene &sc, con
 }
 
 // RAW HIT RECORDS (round 3).  The persistent-wave closest-hit kernel (trace4r.hip) does not commit: a finished lane stores
-//     HITUV = {u, v, FLX_RAW | [FLX_RAW_LIGHT] | (triangle + 1), t}
-// and the commit happens where the record is consumed anyway -- in the fused logic pass of the next iteration (logic.hip: k_logic<FUSE, RAW>),
-// which has the ray in registers and needs the shading attributes next -- or, when anything else wants to look first (a read-back, the
-// separate kernels, the microkernels ...), in k_materialise (api.hip: settle).  A committed record holds the hit index there (>= -1), so
-// bits 31:30 == 01 marks a raw one unambiguously for scenes below 2^29 triangles.
+//     HITUV = {u, v, FLX_RAW | (triangle + 1), t}
+// and the commit -- implicit area-light quad included -- happens where the record is consumed anyway: in the fused logic pass of the next
+// iteration (logic.hip: k_logic<FUSE, RAW>), which has the ray in registers and needs the shading attributes next -- or, when anything else
+// wants to look first (a read-back, the separate kernels, the microkernels ...), in k_materialise (api.hip: settle).  A committed record
+// holds the hit index there (>= -1), so bits 31:30 == 01 marks a raw one unambiguously for scenes below 2^30 triangles.
 #define FLX_RAW       0x40000000u
-#define FLX_RAW_LIGHT 0x20000000u
-#define FLX_RAW_TRI   0x1FFFFFFFu
+#define FLX_RAW_TRI   0x3FFFFFFFu
 __device__ __forceinline__ bool hit_is_raw(uint32_t z) { return (z & 0xC0000000u) == FLX_RAW; }
 __device__ __forceinline__ HitVals hit_values_raw(const Scene &sc, const flx_render_params &p, f3 orig, f3 dir, float4 raw)
 {
-    const uint32_t z = __float_as_uint(raw.z);
-    HitVals h = hit_values<false>(sc, p, orig, dir, raw.w, raw.x, raw.y, (int)(z & FLX_RAW_TRI) - 1);
-    if (z & FLX_RAW_LIGHT) hit_values_light(h, p, orig, dir, raw.w);
-    return h;
+    return hit_values<true>(sc, p, orig, dir, raw.w, raw.x, raw.y, (int)(__float_as_uint(raw.z) & FLX_RAW_TRI) - 1);
 }
 
 struct Stack {

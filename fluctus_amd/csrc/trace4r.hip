@@ -127,31 +127,19 @@ __global__ __launch_bounds__(256) void k_materialise(State st, Scene sc, flx_ren
     }
 }
 
-// The area-light quad, applied AFTER the traversal for scenes that have one (two more triangle tests with their corner set-up: inlined in
-// k_trace4r they cost 30 VGPRs = three waves per SIMD; as a streaming pass they cost ~50 B per ray).
-//  closest hit (src/wf_extrays.cl:28-29, src/intersect.cl:124-155): the quad wins when it is not farther than the triangle found: the raw
-//    record gets the quad's t and FLX_RAW_LIGHT, and whoever commits it (hit_values_raw) applies what commit_hit's light branch does;
-//  any hit (src/wf_shadowrays.cl:32-33): the quad blocks like any triangle; the reference tests it first, the result is the OR either way.
-template <bool ANY_HIT>
+// The area-light quad of the ANY-HIT query, applied after the traversal for scenes that have one (two more triangle tests with their corner
+// set-up: inlined in k_trace4r they cost 30 VGPRs = three waves per SIMD; as a streaming pass ~40 B per ray).  The quad blocks like any
+// triangle (src/wf_shadowrays.cl:32-33); the reference tests it first, the result is the OR either way.  (The closest-hit query's implicit
+// light hit, src/wf_extrays.cl:28-29, is part of the commit: hit_values.)
 __global__ __launch_bounds__(256) void k_lightfix4(State st, Queues qs, flx_render_params p)
 {
-    const uint32_t qlen = ANY_HIT ? qs.counters[FLX_Q_SHADOW] : ext_len(qs);
+    const uint32_t qlen = qs.counters[FLX_Q_SHADOW];
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < qlen; idx += gridDim.x * blockDim.x) {
-        const uint32_t gid = qs.q[ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION][idx];
-        if (ANY_HIT) {
-            if (st.blocked[gid]) continue;
-            const float4 o4 = rd4(st.at(S_SHO, gid)), d4 = rd4(st.at(S_SHD, gid));
-            float tl = o4.w;                                             // shadowRayLen
-            if (light_quad(p.areaLight, ld3(o4), ld3(d4), &tl)) st.blocked[gid] = 1u;
-        } else {
-            const float4 o4 = rd4(st.at(S_ORIG, gid)), d4 = rd4(st.at(S_DIR, gid));
-            float4 raw = rd4t(st.at(S_HITUV, gid));
-            float t = raw.w;
-            if (light_quad(p.areaLight, ld3(o4), ld3(d4), &t)) {
-                raw.w = t; raw.z = __uint_as_float(__float_as_uint(raw.z) | FLX_RAW_LIGHT);
-                wr4(st.at(S_HITUV, gid), raw);
-            }
-        }
+        const uint32_t gid = qs.q[FLX_Q_SHADOW][idx];
+        if (st.blocked[gid]) continue;
+        const float4 o4 = rd4(st.at(S_SHO, gid)), d4 = rd4(st.at(S_SHD, gid));
+        float tl = o4.w;                                                 // shadowRayLen
+        if (light_quad(p.areaLight, ld3(o4), ld3(d4), &tl)) st.blocked[gid] = 1u;
     }
 }
 
@@ -177,7 +165,6 @@ void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
     const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks);
     hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
-    if (p.sampleImpl && p.useAreaLight) hipLaunchKernelGGL(k_lightfix4<false>, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
 }
 
 void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t numCUs)
@@ -198,7 +185,7 @@ void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Sce
         const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks);
         hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
     }
-    if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4<true>, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
+    if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
 }
 
 } // namespace flxd
