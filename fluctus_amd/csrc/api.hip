@@ -19,8 +19,8 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
-void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
-void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int);
+void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
+void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int);
 void launch_materialise(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
@@ -37,7 +37,7 @@ void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
 void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
 void launch_mk_sample_bsdf(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
 void launch_mk_splat(hipStream_t, const State &, const Frame &, const flx_render_params &, uint32_t *, int);
-void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t, uint32_t);
+void launch_end_iteration(hipStream_t, uint32_t *, unsigned long long *, uint32_t *, uint32_t, uint32_t, uint32_t *);
 void launch_bump_extension(hipStream_t, uint32_t *, uint32_t);
 void launch_deinterleave(hipStream_t, const float *, float *, uint32_t, uint32_t, uint32_t);
 }
@@ -100,6 +100,7 @@ struct flx_ctx {
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as any other entry point runs (settle; the calls of the steady-state loop set keepRaw first).
     bool rawHits = false, keepRaw = false;
+    bool cursorDirty[2] = {false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
@@ -259,8 +260,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         if (dalloc(c, c->fixedAllocs, &c->qs.q[q], N)) return fail("hipMalloc(queue)", hipErrorOutOfMemory);
         (void)hipMemsetAsync(c->qs.q[q], 0, N * 4, c->stream);
     }
-    if (dalloc(c, c->fixedAllocs, &c->qs.counters, 8)) return fail("hipMalloc(counters)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->qs.counters, 8) || dalloc(c, c->fixedAllocs, &c->qs.cursors, FLX_NUM_BLOCK_CURSORS * FLX_CURSOR_STRIDE)) return fail("hipMalloc(counters)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->qs.counters, 0, 32, c->stream);
+    (void)hipMemsetAsync(c->qs.cursors, 0, 4 * FLX_NUM_BLOCK_CURSORS * FLX_CURSOR_STRIDE, c->stream);
     const size_t auxStride = logic_aux_stride(num_tasks);          // per list, padded for the scan kernel's uint4 accesses
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * auxStride) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * auxStride))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
@@ -654,7 +656,12 @@ int flx_wf_extend(flx_ctx *c)
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
-        if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) { launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt); c->rawHits = true; }
+        if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) {
+            uint32_t *cur = c->qs.cursors;
+            if (c->cursorDirty[0]) HIPCHK(c, hipMemsetAsync(cur, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream));      // (no k_end_iteration since the last launch)
+            launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, cur);
+            c->cursorDirty[0] = true; c->rawHits = true;
+        }
         else if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
@@ -687,7 +694,12 @@ int flx_wf_shadow(flx_ctx *c)
     {
         ScopedTimer t(c, FLX_K_SHADOW, s);
         uint32_t *spill = overlapped ? c->spill2 : c->spill;
-        if (c->shadowTree == 4 && c->wideOK && c->refillShadow > 0 && !c->statsOn) launch_shadow4r(s, c->st, c->qs, c->sc, c->params, spill, (uint32_t)c->numCUs, c->refillShadow);
+        if (c->shadowTree == 4 && c->wideOK && c->refillShadow > 0 && !c->statsOn) {
+            uint32_t *cur = c->qs.cursors + 8 * FLX_CURSOR_STRIDE;
+            if (c->cursorDirty[1]) HIPCHK(c, hipMemsetAsync(cur, 0, 4 * 8 * FLX_CURSOR_STRIDE, s));
+            launch_shadow4r(s, c->st, c->qs, c->sc, c->params, spill, (uint32_t)c->numCUs, c->refillShadow, cur);
+            c->cursorDirty[1] = true;
+        }
         else if (c->shadowTree == 4 && c->wideOK) launch_shadow4(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
@@ -769,7 +781,14 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
 }
 int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
-int flx_clear_queues(flx_ctx *c) { KEEP_RAW(c); MUTATES(c); c->qs.extPend = 0; c->matQueuesEmpty = true; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream)); return 0; }
+int flx_clear_queues(flx_ctx *c)
+{
+    KEEP_RAW(c); MUTATES(c);
+    c->qs.extPend = 0; c->matQueuesEmpty = true;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
+    return 0;
+}
 
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
@@ -830,7 +849,8 @@ int flx_end_iteration_async(flx_ctx *c)
 {
     KEEP_RAW(c);
     READY(c);
-    launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend);
+    launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend, c->qs.cursors);
+    c->cursorDirty[0] = c->cursorDirty[1] = false;      // (k_end_iteration zeroes the block cursors with the counters)
     c->qs.extPend = 0;
     c->matQueuesEmpty = true;                           // it clears the queue counters
     LAUNCHED(c);

@@ -51,9 +51,17 @@ struct State {
     uint32_t numTasks;
 };
 
+// Block cursors of the persistent traversal kernels (trace4r.hip): one per XCD and kernel, [0..7] closest hit, [8..15] any hit, FLX_CURSOR_STRIDE
+// words apart (every cursor is a hot atomic: each gets a cache line and L2 channel of its own).  A wave takes its next 64-ray block from the list of
+// its own XCD (blocks x, x + 8, x + 16, ...) and from the next XCD's list when its own is exhausted.  Zeroed wherever the queue counters are
+// (flx_clear_queues, k_end_iteration).
+#define FLX_NUM_BLOCK_CURSORS 16
+#define FLX_CURSOR_STRIDE 64
+
 struct Queues {
     uint32_t *q[FLX_NUM_QUEUES];
     uint32_t *counters;           // 8 x u32 (flx_queue_counters)
+    uint32_t *cursors;            // FLX_NUM_BLOCK_CURSORS x FLX_CURSOR_STRIDE u32
     uint32_t extPend;             // lazy extension counter: bit q set = counters[q] entries were appended to the extension queue
                                   // but counters[EXTENSION] has not been bumped yet (see ext_len)
 };

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_state_import(State st, const flo
     st.phase[gid] = __float_as_uint(R(FLX_COL_PHASE));
 }
 
-__global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend)
+__global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend, uint32_t *blockCursors)
 {
     const uint32_t i = threadIdx.x;
     if (i < 8u) {
@@ -223,10 +223,11 @@ __global__ void k_end_iteration(uint32_t *counters, unsigned long long *totals, 
         if (i == FLX_Q_RAYGEN) *cursor = (uint32_t)(((unsigned long long)*cursor + v) % localPixels);
         counters[i] = 0u;
     }
+    if (i >= 8u && i < 8u + FLX_NUM_BLOCK_CURSORS) blockCursors[(i - 8u) * FLX_CURSOR_STRIDE] = 0u;     // block cursors of the persistent traversal kernels (flx_device.h)
 }
-void launch_end_iteration(hipStream_t s, uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend)
+void launch_end_iteration(hipStream_t s, uint32_t *counters, unsigned long long *totals, uint32_t *cursor, uint32_t localPixels, uint32_t extPend, uint32_t *blockCursors)
 {
-    hipLaunchKernelGGL(k_end_iteration, dim3(1), dim3(64), 0, s, counters, totals, cursor, localPixels, extPend);
+    hipLaunchKernelGGL(k_end_iteration, dim3(1), dim3(64), 0, s, counters, totals, cursor, localPixels, extPend, blockCursors);
 }
 
 void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)

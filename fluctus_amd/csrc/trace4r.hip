@@ -4,9 +4,9 @@
 // VALU instructions cost on gfx950 (scripts/ubench/valu_pairs*.hip: everything but mov / mul / add / logic ops issues on ONE of the SIMD's two
 // pipes) IS the kernel time (0.85 ms), and only 26 % of the lanes of those instructions do work: a thread-per-ray wave lives as long as its
 // longest ray (~25 node visits against a mean of 10.5) and, inside it, every descent round lasts as long as its longest descent.  Here
-//   * the grid is the number of waves the machine holds at once; wave w works through the 64-ray blocks w, w + G, w + 2G, ... of the queue
-//     (no atomics: a hot counter sustains only ~88 atomics/us) and hands the next rays of its block to lanes that have finished as soon as
-//     `refillMin` of them are idle;
+//   * the grid is the number of waves the machine holds at once; a wave takes 64-ray blocks of the queue on demand (one atomic per block on
+//     one of eight per-XCD cursors: a single hot counter sustains only ~88 atomics/us) and hands the next rays of its block to lanes that
+//     have finished as soon as `refillMin` of them are idle;
 //   * a descent round ends when `waitMax` lanes stand on a leaf instead of when the last lane does (the lanes still descending simply go on
 //     in the next round).
 // Measured (kitchen, 4 M rays, refillMin 16, waitMax 32): VALU instructions 5.0e8 -> 2.8e8, lanes per instruction 16.7 -> 29.7, kernel time
@@ -36,15 +36,38 @@ namespace flxd {
 #define R_NONE 0xFFFFFFFFu
 
 template <bool ANY_HIT, int ANY_ORDER>
-__global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax)
+__global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax, uint32_t *cursor)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
     const int QID = ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION;
     const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
     const uint32_t *queue = qs.q[QID];
     const uint32_t nblk = (qlen + 63u) >> 6;
-    uint32_t blk = blockIdx.x, pos = 0;              // wave-uniform cursor: current block, rays of it already handed out
+    // Which 64-ray block next.  Rays differ in cost by an order of magnitude (sky vs. foliage), so a static share per wave leaves wave slots
+    // idle: with blocks w, w + G, ... the average wave of the kitchen launch lived 0.42 of the kernel's 0.60 ms.  Blocks are handed out on
+    // demand instead: list x = blocks x, x + 8, x + 16, ... belongs to XCD x (block b runs on XCD b % 8: rays that are neighbours in the queue
+    // stay on one L2), a wave takes the next block of its XCD's list with ONE atomic per 64 rays (8 hot words at ~14 atomics/us each; a
+    // single word saturates at ~88/us, and so do several words of one cache line: the cursors sit 256 B apart -- side by side behind the queue
+    // counters they made the kernel 2.7 x slower) and moves on to the next XCD's list when its own is exhausted.  The ticket for the block
+    // after the current one is taken when the current one is started, so the atomic's round trip is never waited for.
+    uint32_t xcdList = blockIdx.x & 7u, listsTried = 0;
+    auto issue_fetch = [&]() -> uint32_t {            // lane 0 takes a ticket of the current list; nobody waits for it here
+        uint32_t k = 0;
+        if (threadIdx.x == 0) k = atomicAdd(&cursor[xcdList * FLX_CURSOR_STRIDE], 1u);
+        return k;
+    };
+    auto resolve = [&](uint32_t ticket) -> uint32_t { // wave-uniform: the block a ticket stands for, or the first block of another list, or none
+        for (;;) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * 8u + xcdList;
+            if (b < nblk) return b;
+            if (++listsTried >= 8u) return 0xFFFFFFFFu;
+            xcdList = (xcdList + 1u) & 7u;             // this list is exhausted: on to the next XCD's
+            ticket = issue_fetch();
+        }
+    };
+    uint32_t blk = resolve(issue_fetch()), pos = 0;  // wave-uniform: current block, rays of it already handed out
     if (blk >= nblk) return;
+    uint32_t nextTicket = issue_fetch();             // (in flight while the current block is traced)
 
     WStack stk;
     stk.lds = s_stack + threadIdx.x;
@@ -85,7 +108,7 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
                     sp = 0; stk.base = 0; cur = sc.wrootRef;
                 }
                 pos += min(nIdle, avail);
-                if (pos >= blkLen) { blk += gridDim.x; pos = 0; }
+                if (pos >= blkLen) { blk = resolve(nextTicket); pos = 0; if (blk < nblk) nextTicket = issue_fetch(); }
             } else if (nIdle == 64u) break;
         }
         // descent round: lanes on an inner node visit it; the round ends when none is left -- or when `waitMax` lanes stand on a leaf (they
@@ -158,13 +181,13 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
 }
 
 // refill = refillMin | waitMax << 8.  Leaves RAW hit records behind (the caller remembers: api.hip, flx_ctx::rawHits).
-void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill)
+void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor)
 {
     const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
     static int occ = 0;
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
     const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks);
-    hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+    hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
 }
 
 void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t numCUs)
@@ -172,7 +195,7 @@ void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const f
     hipLaunchKernelGGL(k_materialise, dim3(numCUs * 8), dim3(256), 0, s, st, sc, p);
 }
 
-void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill)
+void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor)
 {
     const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
     static int occ[2] = {0, 0};
@@ -180,10 +203,10 @@ void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     // visit order of the any-hit traversal (trace4.hip: launch_shadow4): far -> near when every shadow ray runs toward the environment light
     if (p.useEnvMap && !p.useAreaLight) {
         const uint32_t grid = persistent_grid(k_trace4r<true, 1>, occ[1], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+        hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     } else {
         const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks);
-        hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax);
+        hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     }
     if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
 }
