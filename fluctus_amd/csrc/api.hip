@@ -56,8 +56,8 @@ struct flx_ctx {
     hipEvent_t evPreExt = nullptr, evShadow = nullptr, evPostLogic = nullptr;
     bool overlapOK = false;                     // true between flx_wf_extend and the next enqueue
     bool logicChain = false, logicChainPrev = false;   // only raygen / materials / extend enqueued since flx_wf_logic
-    int overlap = 1;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
-    int overlapOpt = -1;                        // option "overlap": -1 = chosen per scene at flx_upload_scene (pickSchedule), else as set
+    int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
+    int overlapOpt = -1;                        // option "overlap": -1 = the default (pickSchedule), else as set
     uint32_t *spill2 = nullptr;
     // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
     // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
@@ -93,9 +93,9 @@ struct flx_ctx {
     // visit-order ties
     int shadowTree = 4, extendTree = 4;
     // persistent waves with lane refill for the 4-wide kernels (trace4r.hip): 0 = thread-per-ray kernels, n > 0 = refill when n lanes are idle
-    // (closest hit: on by default -- refillMin 16, waitMax 32: kitchen 0.82 -> 0.61 ms per 4 M rays; any hit: per scene, pickSchedule)
+    // (closest hit: on by default -- refillMin 16, waitMax 32: kitchen 0.82 -> 0.61 ms per 4 M rays; any hit: off by default, pickSchedule)
     int refillExt = 16 | (32 << 8), refillShadow = 0;
-    int refillShadowOpt = -1;                   // option "refill_shadow": -1 = per scene, else as set
+    int refillShadowOpt = -1;                   // option "refill_shadow": -1 = the default (off), else as set
     // The persistent-wave extension kernel leaves RAW hit records (flx_trace.h): true from flx_wf_extend until they are committed -- by the
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as any other entry point runs (settle; the calls of the steady-state loop set keepRaw first).
@@ -321,21 +321,17 @@ uint32_t flx_num_tasks(flx_ctx *c) { return c->numTasks; }
 // (an interop caller enqueues its own work behind ours on this stream: a deferred flx_wf_logic / flx_wf_raygen must be in it by then)
 void *flx_stream(flx_ctx *c) { (void)settle(c); return (void *)c->stream; }
 
-// How the two traversals share the machine, chosen per scene unless the options say otherwise (the reference specialises per scene too:
-// it recompiles its kernels with -DBXDF_USE_* at every scene load).  Measured with the persistent-wave extension kernel (one box, Mrays/s):
-//                          shadow || extension    shadow right after logic    serial, any-hit kernel persistent too
-//   kitchen    (35 MB tree)        5421                    5366                        5131
-//   conference (16 MB)             5085                    4848                        4598
-//   courtyard  (0.6 GB)            1896                    1850 (1903 both persistent) 1963
-// A tree that lives in L2 / Infinity Cache: the thread-per-ray shadow kernel fills the tail of the persistent extension kernel (schedule 1).
-// A tree that comes from HBM: both traversals wait for the same misses, co-scheduling buys nothing and the persistent any-hit kernel's
-// fewer instructions do (schedule 0 + refill_shadow).
+// How the two traversals share the machine.  Two persistent kernels cannot run side by side (each fills every wave slot), so the second stream
+// serves the THREAD-PER-RAY any-hit kernel: started right after `logic` (schedule 2) it runs beside genRays / the material kernels and then
+// fills the slots the persistent closest-hit kernel's waves leave as they retire.  Measured with the final round-3 kernels (blocks handed out
+// on demand; profiles/r03_wave_slots_sweep.txt, one box, Mrays/s, schedule 1 / schedule 2 / serial with a persistent any-hit kernel):
+//   kitchen 4951-5249 / 5208-5489 / 4800-4840     conference 4931-4996 / 5017-5019 / 4590-4720     courtyard 2165 / 2181 / 1998-2076
+// (an earlier build with a static share of blocks per wave preferred the serial schedule for the courtyard, whose tree comes from HBM; with
+// balanced waves it does not).  Options "overlap" and "refill_shadow" override; -1 = these defaults.
 static void pickSchedule(flx_ctx *c)
 {
-    const size_t treeBytes = (size_t)c->wideInfo[0] * 64 + (size_t)c->wideInfo[1] * 16;
-    const bool hbmTree = treeBytes > ((size_t)192 << 20);          // well beyond what the 256 MB Infinity Cache keeps beside 0.8 GB of streamed path state
-    c->overlap = c->overlapOpt >= 0 ? c->overlapOpt : (hbmTree ? 0 : 1);
-    c->refillShadow = c->refillShadowOpt >= 0 ? c->refillShadowOpt : (hbmTree ? (16 | (32 << 8)) : 0);
+    c->overlap = c->overlapOpt >= 0 ? c->overlapOpt : 2;
+    c->refillShadow = c->refillShadowOpt >= 0 ? c->refillShadowOpt : 0;
 }
 
 // ---- scene upload: reference wire arrays -> traversal layout -------------------------------

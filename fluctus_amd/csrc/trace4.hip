@@ -62,6 +62,8 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_MIN_WAVES) void k_shadow4(State st
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
     const uint32_t qlen = qs.counters[FLX_Q_SHADOW];
+    // (the shadow queue holds ~3/4 of numTasks, so ~15 k of the 65 k waves exit here at once; a capped grid whose waves stride over the queue
+    //  was measured instead -- 0.315 -> 0.387 ms, two blocks in a row per wave lengthen the tail -- profiles/r03_shadow_grid_cap_ab.txt)
     const uint32_t idx = blockIdx.x * WIDE_BLOCK + threadIdx.x;
     if (idx >= qlen) return;
     const uint32_t gid = qs.q[FLX_Q_SHADOW][idx];

@@ -27,6 +27,7 @@
 // results are bit-identical to those kernels whatever lane or wave a ray lands on (tests/test_gpu_wide.py).
 // Replaces reference kernels traceExtension (src/wf_extrays.cl:5-36) and traceShadow (src/wf_shadowrays.cl:6-38).
 #include "flx_trace4.h"
+#include <cstdlib>
 
 namespace flxd {
 
@@ -68,6 +69,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
     uint32_t blk = resolve(issue_fetch()), pos = 0;  // wave-uniform: current block, rays of it already handed out
     if (blk >= nblk) return;
     uint32_t nextTicket = issue_fetch();             // (in flight while the current block is traced)
+    // the path ids of the current block, one per lane, loaded when the block is taken: a refill then gets its ids from registers (one
+    // cross-lane read) and waits for ONE memory round trip -- the rays -- instead of two
+    uint32_t gidBlk = queue[min((blk << 6) + threadIdx.x, qlen - 1u)];
 
     WStack stk;
     stk.lds = s_stack + threadIdx.x;
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
                 const uint32_t blkLen = min(64u, qlen - (blk << 6));
                 const uint32_t avail = blkLen - pos;
                 const uint32_t rank = mbcnt(idleMask);
+                const uint32_t cand = (uint32_t)__shfl((int)gidBlk, (int)((pos + rank) & 63u), 64);       // (every lane takes part: ds_bpermute reads active lanes only)
                 if (idle && rank < avail) {
-                    gid = queue[(blk << 6) + pos + rank];
+                    gid = cand;
                     const float4 o4 = rd4(st.at(ANY_HIT ? S_SHO : S_ORIG, gid));
                     const float4 d4 = rd4(st.at(ANY_HIT ? S_SHD : S_DIR, gid));
                     r.setup(ld3(o4), ld3(d4), sc.wideClamp);
@@ -108,7 +113,10 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
                     sp = 0; stk.base = 0; cur = sc.wrootRef;
                 }
                 pos += min(nIdle, avail);
-                if (pos >= blkLen) { blk = resolve(nextTicket); pos = 0; if (blk < nblk) nextTicket = issue_fetch(); }
+                if (pos >= blkLen) {
+                    blk = resolve(nextTicket); pos = 0;
+                    if (blk < nblk) { nextTicket = issue_fetch(); gidBlk = queue[min((blk << 6) + threadIdx.x, qlen - 1u)]; }
+                }
             } else if (nIdle == 64u) break;
         }
         // descent round: lanes on an inner node visit it; the round ends when none is left -- or when `waitMax` lanes stand on a leaf (they
@@ -175,7 +183,9 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kernel), WIDE_BLOCK, 0) != hipSuccess || n <= 0) n = 16;
         cached = n;
     }
-    const uint32_t g = numCUs * (uint32_t)cached;
+    int perCU = cached;
+    { static const char *e = getenv("FLX_PERSISTENT_WAVES_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }      // A/B hook: leave wave slots to a concurrent kernel
+    const uint32_t g = numCUs * (uint32_t)perCU;
     const uint32_t blocks = (numTasks + 63u) / 64u;
     return g < blocks ? g : blocks;
 }

@@ -193,14 +193,15 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     DESIGN.md 4.1) | 2: the reference's binary tree in the reference's visit order (bit-exact)
  *   overlap           0 serial | 1 flx_wf_shadow directly after flx_wf_extend runs concurrently with it on a second stream |
  *                     2 as 1, and it starts as soon as `logic` is done when only raygen / materials / extend
- *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip) | -1 (default): 1 or 0, picked at
- *                     flx_upload_scene from the size of the tree (api.hip: pickSchedule); flx_get_option returns the effective value
+ *                     were enqueued since flx_wf_logic (see flx_wf_shadow in api.hip) | -1 (default) = 2; flx_get_option returns the
+ *                     effective value
  *   refill_extend     the closest-hit query on the 4-wide tree as a PERSISTENT kernel (csrc/trace4r.hip): value = refillMin | waitMax << 8
  *                     -- lanes that finished take new rays when refillMin lanes are idle; a descent round ends when waitMax lanes
  *                     stand on a leaf.  Default 16 | 32 << 8; 0 = the thread-per-ray kernel.  Bit-identical results.  The kernel leaves
  *                     RAW hit records; they are committed by the next fused logic pass, or by a separate pass as soon as any call that
  *                     could observe a hit record is made -- no call sees a raw one
- *   refill_shadow     the same for the any-hit query; -1 (default) = picked at flx_upload_scene (on for trees beyond the Infinity Cache)
+ *   refill_shadow     the same for the any-hit query; -1 (default) = 0: two persistent kernels cannot share the machine, so the any-hit
+ *                     kernel stays thread-per-ray and fills the slots the persistent closest-hit kernel's waves leave (api.hip: pickSchedule)
  *   fuse              1 (default): flx_wf_logic is DEFERRED -- launched by the next call on this context; when that call is
  *                     flx_wf_materials (a flx_wf_raygen between the two is deferred along and launched right after), logic and the
  *                     material step of the most common BSDF types run as ONE pass over the path state (logic.hip: k_logic<FUSED>),

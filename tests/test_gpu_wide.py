@@ -253,7 +253,7 @@ def _free_run_default_vs_oracle(workload, n, iterations, start_iterations=0):
     # the shipped defaults: both traversals on the 4-wide tree, persistent-wave extension kernel with RAW hit records, fused logic pass,
     # the stream schedule flx_upload_scene picked for the scene
     assert g.get_option("extend_tree") == 4 and g.get_option("shadow_tree") == 4 and g.get_option("fuse") == 1
-    assert g.get_option("refill_extend") > 0 and g.get_option("overlap") in (0, 1)
+    assert g.get_option("refill_extend") > 0 and g.get_option("overlap") == 2 and g.get_option("refill_shadow") == 0
     for it in range(start_iterations):                  # device alone (cheap), then the oracle takes the state over ...
         cnt = driver.benchmark_iteration(g, npix)
         o.pixel_index_update(npix, int(cnt[Q.RAYGEN]))   # ... the pixel cursor included (replayed: it is host-side state of both)
