@@ -146,6 +146,8 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         }
 
         // consume the light sample generated at the previous vertex (:135-156)
+        // (fetching these four records with the first batch of loads, unconditionally, instead of behind shadowRayBlocked: 110 VGPRs with the
+        //  commit's shading record in flight, no gain -- profiles/r03_logic_nee_early_ab.txt)
         if (st.blocked[gid] == 0u) {
             const float4 le = rd4(st.at(S_LEMIT, gid));
             const float4 lb = rd4(st.at(S_LBSDF, gid));

@@ -345,3 +345,84 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
     assert common.fb_close(a.read_pixels(0), b.read_pixels(0))
     for g in ctx:
         g.close()
+
+
+def test_raw_hit_records_call_patterns():
+    """The persistent-wave extension kernel leaves RAW hit records; the host side of the boundary (api.hip: rawHits / KEEP_RAW / materialise)
+    has to commit them the moment anything but the reference's own loop could observe a hit record -- and only then.  Call sequences that
+    look in between, change options, repeat calls or leave the logic -> genRays -> materials chain are run on the device (shipped defaults)
+    and on the oracle from the same state; the WHOLE exported state, queues and counters must agree after each, and `k_materialise` /
+    the RAW variant of the fused pass must have run exactly when the pattern says so (kernel launch counts from the profile hooks are not
+    available for them, so the distinction is made through the states: a pattern that skipped a needed commit would export raw records).
+    The scene is the one whose 4-wide closest hit has no tie against the oracle (test_wide_closest_hit_lockstep_small: 0 flips)."""
+    d = common.mixed_material_scene()
+    w, h, n = 64, 48, 4096 + 37
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)
+    g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
+    assert g.get_option("refill_extend") > 0
+    npix = w * h
+
+    def cmp(what):
+        cg, co = g.get_counters(), o.get_counters(); g.finish()
+        assert (np.array(cg) == np.array(co)).all(), f"{what}: counters {cg} vs {co}"
+        fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+        assert not fails, f"{what}: " + "; ".join(fails[:4])
+        # no raw marker may ever be visible in an exported hit index (bits 31:30 == 01)
+        hi = g.state_export().view(np.uint32)[COL.HIT_I]
+        assert not (((hi >> 30) & 3) == 1).any(), f"{what}: a RAW hit record was exported"
+
+    def advance(k=1):
+        for _ in range(k):
+            cnts = []
+            for c in (g, o):
+                c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+                cc = c.get_counters(); c.finish(); cnts.append(np.array(cc, copy=True))
+                c.wf_extend(); c.wf_shadow(); c.clear_queues()
+            assert (cnts[0] == cnts[1]).all()
+            for c in (g, o):
+                c.pixel_index_update(npix, int(cnts[1][Q.RAYGEN]))
+
+    advance(3); cmp("3 iterations of the reference's loop (raw records consumed by the fused pass each time)")
+    # a read-back right after the extension kernel, then the loop goes on from the committed records
+    for c in (g, o):
+        c.wf_logic(False); c.wf_raygen(); c.wf_materials(); c.wf_extend()
+    cmp("export right after flx_wf_extend")
+    for c in (g, o):
+        c.wf_shadow(); c.clear_queues(); c.pixel_index_update(npix, 64)
+    advance(1); cmp("loop continued after the in-memory commit")
+    # the extension kernel twice in a row (pathLen += 2, as the reference's kernel would)
+    for c in (g, o):
+        c.wf_logic(False); c.wf_raygen(); c.wf_materials(); c.wf_extend(); c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.pixel_index_update(npix, 64)
+    cmp("two extension launches back to back")
+    # the separate kernels after a persistent extension launch: option change, then logic alone, raygen, materials
+    for c in (g, o):
+        c.wf_logic(False); c.wf_raygen(); c.wf_materials(); c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.pixel_index_update(npix, 64)
+    g.set_option("fuse", 0)
+    advance(2); cmp("fuse 0 after raw records were pending")
+    g.set_option("fuse", 1)
+    advance(1)
+    # chain without genRays: the fused pass may not take raw records (terminated paths would keep them), so they are committed first
+    for c in (g, o):
+        c.wf_logic(False); c.wf_materials(); c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.pixel_index_update(npix, 0)
+    advance(1); cmp("logic -> materials without genRays")
+    # materials first, then genRays; counters and a queue read between the extension kernel and logic; parameters changed in between
+    p2 = p.copy(); p2["maxBounces"] = 3
+    for c in (g, o):
+        c.wf_logic(False); c.wf_materials(); c.wf_raygen(); c.wf_extend(); c.wf_shadow()
+        c.queue_read(Q.EXTENSION); c.clear_queues(); c.set_params(p2); c.pixel_index_update(npix, 17)
+    advance(1)
+    for c in (g, o):
+        c.set_params(p)
+    advance(1); cmp("queue read, parameter change")
+    # the thread-per-ray kernel and the bit-exact binary kernel take over from raw records and hand back
+    for tree, refill in ((4, 0), (2, 0), (4, 16 | (32 << 8))):
+        g.set_option("extend_tree", tree); g.set_option("refill_extend", refill)
+        advance(2); cmp(f"extend_tree {tree}, refill_extend {refill}")
+    # first-frame sequence of Tracer::update (reset, genRays, extension, then three preview iterations with firstIteration set)
+    for c in (g, o):
+        driver.reset_renderer(c)
+        driver.first_frame(c, p, npix)
+    cmp("first frame")
+    advance(2); cmp("after the first frame")
+    assert common.fb_close(g.read_pixels(0), o.read_pixels(0))
+    g.close()
