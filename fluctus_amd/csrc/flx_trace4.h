@@ -191,9 +191,6 @@ __device__ __forceinline__ bool wide_leaf_visit(const float4 *wleaf, const WRay 
     return false;
 }
 
-#ifndef W4_WAIT
-#define W4_WAIT 64          // thread-per-ray kernels: a descent round ends when this many lanes of the wave stand on a leaf (64 = when none descends any more)
-#endif
 template <bool ANY_HIT, bool STATS, int ANY_ORDER = 0>
 __device__ __forceinline__ bool traverse4(const Scene &sc, WStack &stk, f3 orig, f3 dir, float &tbest, float &ubest, float &vbest,
                                           int &tribest, uint32_t &nInner, uint32_t &nTri, uint32_t &nLeaf, unsigned long long *wstats = nullptr)
@@ -206,35 +203,19 @@ __device__ __forceinline__ bool traverse4(const Scene &sc, WStack &stk, f3 orig,
     uint32_t cur = sc.wrootRef;
     for (;;) {
         FLX_WAVE_TICK(0);
-        if (W4_WAIT >= 64) {
-            while (!(cur & FLX_WIDE_LEAF_BIT)) {
-                FLX_WAVE_TICK(1);
-                if (STATS) nInner++;
-                wide_node_visit<ANY_HIT, ANY_ORDER>(wn, stk, r, tbest, sp, cur);
-            }
-        } else {
-            // the lanes that reached a leaf do not wait for the longest descent of the wave: the round ends when W4_WAIT of them stand on one
-            // (trace4r.hip measured what that is worth in the persistent kernel: -33 % instructions); the others go on in the next round
-            for (;;) {
-                const bool inner = !(cur & FLX_WIDE_LEAF_BIT);
-                const uint64_t mI = __ballot(inner);
-                if (mI == 0ull) break;
-                if ((int)__popcll(__ballot(!inner)) >= W4_WAIT) break;
-                if (inner) {
-                    FLX_WAVE_TICK(1);
-                    if (STATS) nInner++;
-                    wide_node_visit<ANY_HIT, ANY_ORDER>(wn, stk, r, tbest, sp, cur);
-                }
-            }
+        // (ending the descent round early -- when N lanes stand on a leaf -- is what halves the persistent kernel's instruction count
+        //  (trace4r.hip); WITHOUT lane refill it loses: k_shadow4 0.315 -> 0.35-0.38 ms for N = 32 ... 8, profiles/r03_shadow_wait_ab.txt)
+        while (!(cur & FLX_WIDE_LEAF_BIT)) {
+            FLX_WAVE_TICK(1);
+            if (STATS) nInner++;
+            wide_node_visit<ANY_HIT, ANY_ORDER>(wn, stk, r, tbest, sp, cur);
         }
         if (cur == FLX_RAY_DONE) break;
-        if (W4_WAIT >= 64 || (cur & FLX_WIDE_LEAF_BIT)) {
-            FLX_WAVE_TICK(2);
-            if (STATS) nLeaf++;
-            if (wide_leaf_visit<ANY_HIT, STATS>(sc.wleaf, r, cur, tbest, ubest, vbest, tribest, nTri, wstats)) return true;
-            cur = stk.pop(sp);
-            if (cur == FLX_RAY_DONE) break;
-        }
+        FLX_WAVE_TICK(2);
+        if (STATS) nLeaf++;
+        if (wide_leaf_visit<ANY_HIT, STATS>(sc.wleaf, r, cur, tbest, ubest, vbest, tribest, nTri, wstats)) return true;
+        cur = stk.pop(sp);
+        if (cur == FLX_RAY_DONE) break;
     }
     return false;
 #undef FLX_WAVE_TICK
