@@ -82,6 +82,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
         rayDirection = normalize(fp - rayOrig);
 
+        // (temporal instead of non-temporal stores here: within the run-to-run spread, profiles/r03_raygen_temporal_ab.txt)
         wr4(st.at(S_ORIG, gid), mk4(rayOrig, 1.0f));                  // lastPdfW = 1
         wr4(st.at(S_DIR, gid), mk4u(rayDirection, FLX_FRESH | 0u));   // pathLen = 0; the rest of init_path_state's resets are
         wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), FLX_FRESH | localIdx)); // implied by the two flags (flx_device.h), not stored

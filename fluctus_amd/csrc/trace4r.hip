@@ -44,9 +44,9 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
     const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
     const uint32_t *queue = qs.q[QID];
     const uint32_t nblk = (qlen + 63u) >> 6;
-    // Which 64-ray block next.  Rays differ in cost by an order of magnitude (sky vs. foliage), so a static share per wave leaves wave slots
-    // idle: with blocks w, w + G, ... the average wave of the kitchen launch lived 0.42 of the kernel's 0.60 ms.  Blocks are handed out on
-    // demand instead: list x = blocks x, x + 8, x + 16, ... belongs to XCD x (block b runs on XCD b % 8: rays that are neighbours in the queue
+    // Which 64-ray block next.  Rays differ in cost by an order of magnitude (sky vs. foliage), so a static share per wave (blocks w, w + G, ...)
+    // leaves wave slots idle towards the end of the launch (courtyard: 1.60 -> 1.50 ms with this; kitchen and conference unchanged).  Blocks
+    // are handed out on demand: list x = blocks x, x + 8, x + 16, ... belongs to XCD x (block b runs on XCD b % 8: rays that are neighbours in the queue
     // stay on one L2), a wave takes the next block of its XCD's list with ONE atomic per 64 rays (8 hot words at ~14 atomics/us each; a
     // single word saturates at ~88/us, and so do several words of one cache line: the cursors sit 256 B apart -- side by side behind the queue
     // counters they made the kernel 2.7 x slower) and moves on to the next XCD's list when its own is exhausted.  The ticket for the block

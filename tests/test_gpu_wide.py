@@ -426,3 +426,41 @@ def test_raw_hit_records_call_patterns():
     advance(2); cmp("after the first frame")
     assert common.fb_close(g.read_pixels(0), o.read_pixels(0))
     g.close()
+
+
+def test_persistent_kernels_with_empty_and_tiny_queues():
+    """Edge cases of the block hand-out: an EMPTY extension / shadow queue (every wave finds its XCD's list exhausted, tries the other seven
+    and leaves), a queue of one ray, one of 65 (a full block and a block of one), with both traversals persistent; state and counters as the
+    oracle's after each."""
+    d = common.mixed_material_scene()
+    w, h, n = 16, 8, 1024
+    p = common.scene_params(d, w, h, maxBounces=4, useAreaLight=1, useEnvMap=1, wfSeparateQueues=1)
+    g, o = _ctxs(d, p, n, env=host.synthetic_sky(64, 32))
+    g.set_option("refill_shadow", 16 | (32 << 8))
+    for c in (g, o):                                   # nothing generated yet: every queue is empty
+        c.wf_extend(); c.wf_shadow()
+    assert not common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+    assert (np.array(g.get_counters()) == np.array(o.get_counters())).all()
+    g.finish()
+    for it in range(3):
+        for c in (g, o):
+            c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+        cnt = np.array(o.get_counters(), copy=True)
+        q = o.queue_read(Q.EXTENSION)[:int(cnt[Q.EXTENSION])].copy()
+        for keep in (0, 1, 65):                        # trace only the first `keep` rays of the queue: on BOTH sides, from the same state
+            for c in (g, o):
+                cc = cnt.copy(); cc[Q.EXTENSION] = min(keep, q.size); cc[Q.SHADOW] = min(keep, int(cnt[Q.SHADOW]))
+                c.set_counters(cc)
+            common.sync(g, o)
+            for c in (g, o):
+                c.wf_extend(); c.wf_shadow()
+            g.finish()
+            fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+            assert not fails, f"it{it}, {keep} rays: " + "; ".join(fails[:3])
+        for c in (g, o):
+            c.set_counters(cnt)
+        common.sync(g, o)
+        for c in (g, o):
+            c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.pixel_index_update(w * h, int(cnt[Q.RAYGEN]))
+    assert not common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+    g.close()
