@@ -360,7 +360,7 @@ def main():
     # fabric-side bytes of the extension kernel per launch, from the committed PMC capture of THIS workload (profiles/traffic_<workload>.json,
     # written by scripts/profile_r03.sh: separate --pmc passes, request counters by size = 2 x FETCH_SIZE + WRITE_SIZE with the guide's gfx950
     # correction); only quoted for the configuration it was captured on
-    traffic = traffic_lines = None
+    traffic = traffic_lines = traffic_lanes = traffic_valu = None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(tpath):
         try:
@@ -369,6 +369,8 @@ def main():
                     and tj.get("refill_extend", 0) == ctx.get_option("refill_extend")):
                 traffic = tj.get("extend_hbm_bytes_per_launch")
                 traffic_lines = tj.get("extend_read_requests_128B")
+                traffic_lanes = tj.get("extend_lanes_per_valu_instruction")
+                traffic_valu = tj.get("extend_valu_instructions")
         except Exception:
             traffic = None
 
@@ -477,7 +479,10 @@ def main():
                 "avg_inner_visits": st["ext_inner"] / max(1, st["ext_rays"]),
                 "avg_tri_tests": st["ext_tri"] / max(1, st["ext_rays"]),
                 "hit_fraction": st["ext_hits"] / max(1, st["ext_rays"]),
-                "simd_efficiency": simd,
+                # from the same PMC capture: SQ_INSTS_VALU per launch and SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU of the kernel that runs
+                "valu_instructions_per_launch": traffic_valu, "lanes_per_valu_instruction": traffic_lanes,
+                # wave-level trip counts of the thread-per-ray BINARY kernels' counting variants (the reference traversal on the same rays)
+                "simd_efficiency_reference_traversal": simd,
                 "concurrent_traversal_span_ms": (span_ms / span_n) if span_n else None}
     if rank == 0:
         line = {

@@ -60,6 +60,8 @@ if ext:
          "extend_read_requests_128B": t["read_requests_128B"], "extend_read_requests_64B": t["read_requests_64B"], "extend_write_requests_64B": t["write_requests_64B"],
          "extend_write_requests_32B": t["write_requests_32B"], "fetch_size_kib": t["fetch_size_kib"], "write_size_kib": t["write_size_kib"],
          "companion_kernels_bytes": extra_k,
+         "extend_valu_instructions": acc[ext].get("SQ_INSTS_VALU", [0, 1])[0] / max(1, acc[ext].get("SQ_INSTS_VALU", [0, 1])[1]) or None,
+         "extend_lanes_per_valu_instruction": (acc[ext]["SQ_THREAD_CYCLES_VALU"][0] / acc[ext]["SQ_INSTS_VALU"][0]) if acc[ext].get("SQ_INSTS_VALU", [0])[0] else None,
          "correction": "gfx950 guide: FETCH_SIZE = TCC_EA0_RDREQ x 64 B although the requests are 128 B -> read bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B; write bytes = 64 x WRREQ_64B + 32 x the rest.  Fabric-side counts: Infinity-Cache hits are included, HBM proper is lower.",
          "extend_hbm_bytes_per_launch": t["read_bytes"] + t["write_bytes"] + sum(extra_k.values())}
     json.dump(j, open(os.path.join(prof, f"traffic_{wl}.json"), "w"), indent=1)
