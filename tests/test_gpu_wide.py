@@ -312,6 +312,36 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
+@pytest.mark.parametrize("workload", ["conference", "courtyard-1440p"])
+def test_bench_launch_chain_vs_oracle_full_size(workload):
+    """The launch chain bench.py times, untouched: logic -> genRays -> materials -> extension -> shadow -> clear, nothing looking at the
+    state in between, so that the persistent extension kernel's RAW hit records are committed by the next fused logic pass
+    (k_logic<FUSE, RAW>) and never by k_materialise -- the free runs above export the state after every extension launch and therefore
+    take the other route.  Device and ORACLE free-run BASELINE's configuration at 1 M paths: queue counters after every iteration, the
+    whole path state every fifth iteration (that export commits the pending records in memory; the four iterations before it went
+    through the RAW pass), the framebuffer at the end.  No resynchronisation: a tie resolved the other way would fork the two runs at
+    once -- the two scenes are the ones whose default path showed no flip in 10.5 M rays (test_default_path_free_run_vs_oracle_full_size);
+    the kitchen (1 flip) is covered by that test plus test_refill_kernels_are_bit_identical_to_thread_per_ray.
+    FLX_SOAK_ITERS lengthens the run (default 15)."""
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    iters = int(os.environ.get("FLX_SOAK_ITERS", "15"))
+    g, o = _ctxs(d, p, n, env=env)
+    assert g.get_option("refill_extend") > 0 and g.get_option("fuse") == 1 and g.get_option("extend_tree") == 4
+    rays = 0
+    for it in range(iters):
+        cg, co = driver.benchmark_iteration(g, npix), driver.benchmark_iteration(o, npix)
+        assert (cg == co).all(), f"{workload} it{it}: counters {cg} vs {co}"
+        rays += int(co[Q.EXTENSION]) + int(co[Q.SHADOW])
+        if it % 5 == 4 or it == iters - 1:
+            fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
+            assert not fails, f"{workload} after {it + 1} iterations: " + "; ".join(fails[:4])
+    assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
+    _report(f"bench_chain_vs_oracle_{workload}", {"paths": n, "iterations": iters, "rays": rays, "state_and_counters_identical": True})
+    g.close()
+
+
 # refill option = refillMin | waitMax << 8 (trace4r.hip)
 @pytest.mark.parametrize("workload,refill", [("kitchen", 16 | (32 << 8)), ("conference", 8 | (16 << 8)), ("kitchen", 48 | (8 << 8)), ("kitchen", 16),
                                              ("courtyard-1440p", 16 | (24 << 8))])
