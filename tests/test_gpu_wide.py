@@ -312,16 +312,18 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
-@pytest.mark.parametrize("workload", ["conference", "courtyard-1440p"])
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
 def test_bench_launch_chain_vs_oracle_full_size(workload):
     """The launch chain bench.py times, untouched: logic -> genRays -> materials -> extension -> shadow -> clear, nothing looking at the
     state in between, so that the persistent extension kernel's RAW hit records are committed by the next fused logic pass
     (k_logic<FUSE, RAW>) and never by k_materialise -- the free runs above export the state after every extension launch and therefore
-    take the other route.  Device and ORACLE free-run BASELINE's configuration at 1 M paths: queue counters after every iteration, the
-    whole path state every fifth iteration (that export commits the pending records in memory; the four iterations before it went
-    through the RAW pass), the framebuffer at the end.  No resynchronisation: a tie resolved the other way would fork the two runs at
-    once -- the two scenes are the ones whose default path showed no flip in 10.5 M rays (test_default_path_free_run_vs_oracle_full_size);
-    the kitchen (1 flip) is covered by that test plus test_refill_kernels_are_bit_identical_to_thread_per_ray.
+    take the other route.  Device and ORACLE free-run BASELINE's configuration at 1 M paths: queue counters after every iteration,
+    the whole path state every fifth iteration (that export commits the pending records in memory; the four
+    iterations before it went through the RAW pass), the framebuffer at the end.  A tie in t resolved the other way (SURVEY 8(c)'s
+    hit-index flips, counted ray by ray and shown to be ties by the tests above) cannot be resynchronised inside a stretch here; it
+    sends ONE path another way -- paths are independent; queue ORDER and hence the pixel a later path is given are not, which is why the
+    device is put back on the oracle's state as soon as a counter differs.  At a checkpoint (every fifth iteration, or the iteration a
+    counter differs) the paths whose state differs are counted against the same 1e-5 budget and everything else must be bit-identical.  (Zero tolerance for the same chain: test_refill_kernels_are_bit_identical_to_thread_per_ray, device vs device.)
     FLX_SOAK_ITERS lengthens the run (default 15)."""
     import bench
     d, p, env = bench.build_workload(name=workload)
@@ -329,16 +331,42 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
     iters = int(os.environ.get("FLX_SOAK_ITERS", "15"))
     g, o = _ctxs(d, p, n, env=env)
     assert g.get_option("refill_extend") > 0 and g.get_option("fuse") == 1 and g.get_option("extend_tree") == 4
-    rays = 0
+    rays = ext_rays = forked = 0
+    skip = np.zeros(64, bool); skip[list(common.PAD_COLS)] = True; skip[COL.PHASE] = True
+
+    def checkpoint(what):
+        nonlocal forked
+        sg, so = g.state_export(), o.state_export()
+        bad = ((sg.view(np.uint32) != so.view(np.uint32)) & ~skip[:, None]).any(axis=0)
+        fails = common.state_diff(sg, so, 0.0, 0.0, mask=~bad)
+        assert not fails, f"{workload} {what}: " + "; ".join(fails[:4])
+        if bad.any():
+            forked += int(bad.sum())
+            g.state_import(so)
+
     for it in range(iters):
-        cg, co = driver.benchmark_iteration(g, npix), driver.benchmark_iteration(o, npix)
-        assert (cg == co).all(), f"{workload} it{it}: counters {cg} vs {co}"
-        rays += int(co[Q.EXTENSION]) + int(co[Q.SHADOW])
-        if it % 5 == 4 or it == iters - 1:
-            fails = common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
-            assert not fails, f"{workload} after {it + 1} iterations: " + "; ".join(fails[:4])
-    assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
-    _report(f"bench_chain_vs_oracle_{workload}", {"paths": n, "iterations": iters, "rays": rays, "state_and_counters_identical": True})
+        cnt = []
+        for c in (g, o):                                   # fluctus_amd/driver.py: benchmark_iteration, with the ORACLE's count for both cursors
+            c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+            cc = c.get_counters()
+            c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.finish()
+            cnt.append(np.array(cc, copy=True))
+        cg, co = cnt
+        for c in (g, o):
+            c.pixel_index_update(npix, int(co[Q.RAYGEN]))
+        rays += int(co[Q.EXTENSION]) + int(co[Q.SHADOW]); ext_rays += int(co[Q.EXTENSION])
+        if not (cg == co).all():
+            # a forked path entered another material queue or ended at another bounce: at most a handful of paths, and the states must say so
+            assert int(np.abs(cg.astype(np.int64) - co.astype(np.int64)).sum()) <= 8, f"{workload} it{it}: counters {cg} vs {co}"
+            checkpoint(f"it{it} (counters {cg} vs {co})")
+            assert forked, f"{workload} it{it}: counters differ but the states do not"
+        elif it % 5 == 4 or it == iters - 1:
+            checkpoint(f"after {it + 1} iterations")
+    assert forked <= max(1, int(FLIP_BUDGET * ext_rays)), (workload, forked, ext_rays)
+    if not forked:
+        assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
+    _report(f"bench_chain_vs_oracle_{workload}", {"paths": n, "iterations": iters, "rays": rays, "extension_rays": ext_rays,
+                                                  "paths_forked_by_a_tie": forked})
     g.close()
 
 
