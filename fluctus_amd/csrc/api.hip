@@ -246,16 +246,11 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         for (int r = 0; r < S_NUM_REC; r++) c->st.rec[r] = line[group[r][0]] + group[r][1];
     }
 #else
-    {
-        // A/B hook (experiment): FLX_STATE_STAGGER=<float4 elements> starts record array r at r * stagger elements into its allocation, so that
-        // the twelve streams of one path id do not sit at the same offset of twelve equally aligned allocations
-        size_t stagger = 0;
-        if (const char *e = getenv("FLX_STATE_STAGGER")) stagger = (size_t)atol(e);
-        for (int r = 0; r < S_NUM_REC; r++) {
-            if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N + stagger * r)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
-            c->st.rec[r] += stagger * r;
-            (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
-        }
+    // (staggering the twelve arrays inside their allocations -- 272 / 4112 / 65808 elements per array -- changes nothing: the fused pass lands on
+    //  one of three levels, 0.457 / 0.479 / 0.507 ms, from one process to the next with or without it; profiles/r03_state_stagger_ab.txt)
+    for (int r = 0; r < S_NUM_REC; r++) {
+        if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
+        (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
     }
 #endif
     if (dalloc(c, c->fixedAllocs, &c->st.phase, N) || dalloc(c, c->fixedAllocs, &c->mkStats, 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
