@@ -247,7 +247,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     }
 #else
     // (staggering the twelve arrays inside their allocations -- 272 / 4112 / 65808 elements per array -- changes nothing: the fused pass lands on
-    //  one of three levels, 0.457 / 0.479 / 0.507 ms, from one process to the next with or without it; profiles/r03_state_stagger_ab.txt)
+    //  one of three levels, 0.457 / 0.479 / 0.507 ms, from one process to the next with or without it, and so does ONE allocation for all twelve; profiles/r03_state_stagger_ab.txt, r03_state_slab_ab.txt)
     for (int r = 0; r < S_NUM_REC; r++) {
         if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
         (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
