@@ -365,7 +365,10 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
             areaAll += a;
             if (t.matId >= 0 && (size_t)t.matId < nmat && mats[t.matId].type == FLX_BXDF_DIFFUSE) areaDiffuse += a;
         }
-        c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.5 * areaAll) ? 31 : 1;
+        // Round 3 (persistent closest hit, RAW commit in the pass, shadow rays on the second stream; profiles/r03_fuse_set_ab.txt, same box, diffuse ->
+        // all): courtyard (65 % diffuse) 2158 -> 2258 and 2221 -> 2274 Mrays/s at 1440p, 2088 -> 2167 and 2189 -> 2200 at 2160p -- a third of
+        // its paths took the second trip -- kitchen (96 %) 5297 -> 5152 and 5485 -> 5198.  Hence all types below 3/4 diffuse (round 2: 1/2).
+        c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.75 * areaAll) ? 31 : 1;
         // ... and the order in which the fused pass lists the continuing paths in the extension queue (logic.hip: k_queue_scatter): one
         // segment per material queue, as the separate kernels append them, or all of them by path id.  Same-box A/B, Mrays/s segments ->
         // path id: conference 4318 -> 4446 (+3 %: three BSDF types of similar weight, the segments cut the id order into thirds),
