@@ -146,22 +146,28 @@ def test_wide_tree_edge_cases_single_leaf_and_deep_chain():
     d.nodes, d.indices = nodes, np.arange(nt, dtype=np.uint32)
     d.world_radius = float(0.5 * np.linalg.norm(sufmax[0] - sufmin[0]))
     p = common.scene_params(d, 32, 32, maxBounces=3)
-    g, o = _ctxs(d, p, 1024)
-    info = g.scene_info()
-    assert info["binary_depth"] == nt - 1 and info["wide_stack_bound"] > 16 and info["spill_levels"] >= info["binary_depth"] + 1 - 16
-    rays = flips = 0
-    for it in range(6):
-        for fn in (lambda c: c.wf_logic(False), lambda c: c.wf_raygen(), lambda c: c.wf_materials()):
-            common.sync(g, o); fn(g); fn(o)
-        cnt = o.get_counters().copy()
-        common.sync(g, o)
-        r, f = _extend_flips(g, o, f"chain it{it}"); rays += r; flips += f
-        common.sync(g, o)
-        g.wf_shadow(); o.wf_shadow(); g.finish()
-        assert np.array_equal(g.state_export().view(np.uint32)[COL.SHADOW_BLOCKED], o.state_export().view(np.uint32)[COL.SHADOW_BLOCKED])
-        for c in (g, o):
-            c.clear_queues(); c.pixel_index_update(32 * 32, int(cnt[Q.RAYGEN]))
-    assert flips == 0, (rays, flips)
+    # the stack pages through the spill area in the persistent closest-hit kernel (default), in the thread-per-ray any-hit kernel (default)
+    # and, second pass, in the persistent any-hit kernel and the thread-per-ray closest-hit kernel
+    for refill_ext, refill_sh in ((None, None), (0, 16 | (32 << 8))):
+        g, o = _ctxs(d, p, 1024)
+        if refill_ext is not None:
+            g.set_option("refill_extend", refill_ext); g.set_option("refill_shadow", refill_sh)
+        info = g.scene_info()
+        assert info["binary_depth"] == nt - 1 and info["wide_stack_bound"] > 16 and info["spill_levels"] >= info["binary_depth"] + 1 - 16
+        rays = flips = 0
+        for it in range(6):
+            for fn in (lambda c: c.wf_logic(False), lambda c: c.wf_raygen(), lambda c: c.wf_materials()):
+                common.sync(g, o); fn(g); fn(o)
+            cnt = o.get_counters().copy()
+            common.sync(g, o)
+            r, f = _extend_flips(g, o, f"chain it{it}"); rays += r; flips += f
+            common.sync(g, o)
+            g.wf_shadow(); o.wf_shadow(); g.finish()
+            assert np.array_equal(g.state_export().view(np.uint32)[COL.SHADOW_BLOCKED], o.state_export().view(np.uint32)[COL.SHADOW_BLOCKED])
+            for c in (g, o):
+                c.clear_queues(); c.pixel_index_update(32 * 32, int(cnt[Q.RAYGEN]))
+        assert flips == 0, (rays, flips)
+        g.close()
 
 
 @pytest.mark.parametrize("workload", ["kitchen", "conference"])
