@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_lightfix4(State st, Queues qs, flx_rend
 
 // grid = resident waves of the device for this kernel (occupancy x CUs), capped by the number of 64-ray blocks
 template <class K>
-static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t numTasks)
+static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t numTasks, const char *capEnv = nullptr)
 {
     if (cached == 0) {
         int n = 0;
@@ -185,6 +185,7 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
     }
     int perCU = cached;
     { static const char *e = getenv("FLX_PERSISTENT_WAVES_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }      // A/B hook: leave wave slots to a concurrent kernel
+    if (capEnv) { const char *e = getenv(capEnv); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }                          // (per kernel family)
     const uint32_t g = numCUs * (uint32_t)perCU;
     const uint32_t blocks = (numTasks + 63u) / 64u;
     return g < blocks ? g : blocks;
@@ -196,7 +197,7 @@ void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
     static int occ = 0;
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
-    const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks);
+    const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_EXT");
     hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
 }
 
@@ -212,10 +213,10 @@ void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
     // visit order of the any-hit traversal (trace4.hip: launch_shadow4): far -> near when every shadow ray runs toward the environment light
     if (p.useEnvMap && !p.useAreaLight) {
-        const uint32_t grid = persistent_grid(k_trace4r<true, 1>, occ[1], numCUs, st.numTasks);
+        const uint32_t grid = persistent_grid(k_trace4r<true, 1>, occ[1], numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_SHADOW");
         hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     } else {
-        const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks);
+        const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_SHADOW");
         hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     }
     if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
