@@ -100,6 +100,15 @@ def algorithmic_bytes(stats):
     return ext, sh
 
 
+def capture_key(args, ctx, p, C=1):
+    """What a PMC capture of the extension kernel depends on (see main(): roofline)."""
+    from fluctus_amd import build
+    return {"workload": args.workload, "width": int(p["width"]), "height": int(p["height"]), "max_bounces": int(p["maxBounces"]),
+            "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
+            "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
+            "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"), "source_hash": build.source_hash()}
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (the GPU box reports 256 logical CPUs but grants 16 through cpu.max)."""
@@ -151,6 +160,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the headline is the MEDIAN window (all of them are in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -254,25 +264,36 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # BASELINE.md 2 / SURVEY 8(d): the timed window starts on a STATIONARY queue mix, i.e. after >= 2 x maxBounces iterations from reset
+    # (before that no path has reached maxBounces and the wave of first terminations would fall inside the window).  --warmup is honoured
+    # when it asks for more; the line reports what was run as `settle_iterations` and echoes the flag as `warmup`.
+    settle = max(args.warmup, 2 * int(p["maxBounces"]) + 2)
+    for _ in range(settle):
         step_async(ctx)
     ctx.finish()
     ctx.counter_totals(reset=True)
     ctx.profile_reset()
     ctx.profile_enable(args.kernel_timing)
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_async(ctx)
-    ctx.finish()
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
+    # `--windows` back-to-back windows of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides; a window is
+    # ~0.1 s of GPU time, one sample of it moves by a few per cent from run to run, so the headline is the median window
+    nwin = max(1, args.windows)
+    win_elapsed, win_tot = [], []
+    for _w in range(nwin):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_async(ctx)
+        ctx.finish()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        win_elapsed.append(t1 - t0)
+        win_tot.append(np.array(ctx.counter_totals(reset=True), dtype=np.float64))
     ctx.profile_enable(False)
 
-    tot = ctx.counter_totals(reset=True)
+    tot = np.sum(win_tot, axis=0)                     # all windows: what the event-timed kernel averages cover
     prof = ctx.profile_get()
     # kernels not timed inside the timed region (--kernel-timing 2 times only the trace kernels there, 0 none): averages from
     # an extra UNTIMED pass over the same steady state, so the JSON line still carries every kernel
@@ -297,17 +318,21 @@ def main():
     alone_ms, alone_n = ctx.profile_get()["extend"]
     ctx.set_option("overlap", args.overlap)
     ctx.counter_totals(reset=True)
-    rays_local = float(tot[1]) + float(tot[2])
-    elapsed = t1 - t0
+    # per window: elapsed = max over ranks, rays = sum over ranks
+    wins = np.array([[e, t[0], t[1], t[2]] for e, t in zip(win_elapsed, win_tot)], dtype=np.float64)      # [window][elapsed, primary, extension, shadow]
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([rays_local, float(tot[0]), float(tot[1]), float(tot[2])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        rays_total, prim, ext, sh = [float(x) for x in rr.tolist()]
-    else:
-        rays_total, prim, ext, sh = rays_local, float(tot[0]), float(tot[1]), float(tot[2])
+        te = torch.tensor(wins[:, 0].copy(), dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        tr = torch.tensor(wins[:, 1:].copy(), dtype=torch.float64, device="cuda")
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        wins = np.concatenate([te.cpu().numpy()[:, None], tr.cpu().numpy()], axis=1)
+    win_mrays = (wins[:, 2] + wins[:, 3]) / wins[:, 0] / 1e6
+    order = np.argsort(win_mrays)
+    med = int(order[len(order) // 2]) if len(order) % 2 else int(order[len(order) // 2 - 1])      # (even count: the lower middle window -- a measured one)
+    elapsed = float(wins[med, 0])
+    prim, ext, sh = float(wins[med, 1]), float(wins[med, 2]), float(wins[med, 3])
+    rays_total = ext + sh
+    ext_all = float(wins[:, 2].sum())                  # extension rays of all windows and ranks
 
     # ---- roofline of the dominant kernel (traceExtension): algorithmic bytes / HIP-event time
     # visit counts come from an UNTIMED pass of the counting kernel variants over the same steady state
@@ -348,31 +373,38 @@ def main():
         own_bytes_per_ray = (84 * st_own["ext_rays"] + 64 * st_own["ext_inner"] + 32 * own_leaf["ext_leaf"] + 48 * st_own["ext_tri"]
                              + 64 * st_own["ext_hits"]) / max(1, st_own["ext_rays"])
     ext_ms, ext_n = prof["extend"]
-    rays_per_launch = ext / world / C / max(1, args.steps)
+    rays_per_launch = ext_all / world / C / max(1, args.steps * nwin)
     achieved = (bytes_per_ext_ray * rays_per_launch) / (ext_ms / max(1, ext_n) * 1e-3) / 1e9 if ext_ms > 0 else 0.0
     # k_extend shares the machine with the concurrent k_shadow; the pair's span gives the combined traversal rate
     span_ms, span_n = prof.get("trace_span", (0.0, 0))
     bytes_per_sh_ray = sh_bytes / max(1, st["shadow_rays"])
     combined = None
     if span_n:
-        combined_bytes = bytes_per_ext_ray * rays_per_launch + bytes_per_sh_ray * (sh / world / C / max(1, args.steps))
+        combined_bytes = bytes_per_ext_ray * rays_per_launch + bytes_per_sh_ray * (float(wins[:, 3].sum()) / world / C / max(1, args.steps * nwin))
         combined = combined_bytes / (span_ms / span_n * 1e-3) / 1e9
     # fabric-side bytes of the extension kernel per launch, from the committed PMC capture of THIS workload (profiles/traffic_<workload>.json,
-    # written by scripts/profile_r03.sh: separate --pmc passes, request counters by size = 2 x FETCH_SIZE + WRITE_SIZE with the guide's gfx950
-    # correction); only quoted for the configuration it was captured on
+    # written by scripts/profile_round.sh: separate --pmc passes, request counters by size = 2 x FETCH_SIZE + WRITE_SIZE with the guide's gfx950
+    # correction).  A capture is quoted only for the exact configuration AND kernel sources it was taken on: it carries `capture_key`
+    # (workload, resolution, bounces, paths in flight, trees, refill / overlap / fused-pass settings and a hash of csrc/* + include/*.h);
+    # any difference makes it stale and the line says which keys differ instead of quoting it.
     traffic = traffic_lines = traffic_lanes = traffic_valu = None
+    traffic_stale = None
+    key = capture_key(args, ctx, p, C)
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if (tj.get("num_tasks") == args.num_tasks // C and tj.get("workload") == args.workload and tj.get("extend_tree") == args.extend_tree
-                    and tj.get("refill_extend", 0) == ctx.get_option("refill_extend")):
+            have = tj.get("capture_key") or {}
+            diff = sorted(k for k in key if have.get(k) != key[k])
+            if not diff:
                 traffic = tj.get("extend_hbm_bytes_per_launch")
                 traffic_lines = tj.get("extend_read_requests_128B")
                 traffic_lanes = tj.get("extend_lanes_per_valu_instruction")
                 traffic_valu = tj.get("extend_valu_instructions")
-        except Exception:
-            traffic = None
+            else:
+                traffic_stale = diff
+        except Exception as e:
+            traffic, traffic_stale = None, [f"unreadable: {e}"]
 
     # ---- multi-GPU: gather the radiance tiles over RCCL (outside the timed region)
     gather_ms = None
@@ -446,23 +478,23 @@ def main():
     alone_s = alone_ms / max(1, alone_n) * 1e-3
     own_bytes = own_bytes_per_ray * rays_per_launch if own_bytes_per_ray else None
     contract_bytes = bytes_per_ext_ray * rays_per_launch
-    # `achieved` / `frac`: bytes that really cross the L2 <-> fabric boundary for this kernel (PMC capture of this workload) over the launch
-    # time measured live -- the north-star's own definition ("rocprof-reported HBM bandwidth in the traversal kernel").  Without a matching
-    # capture: the bytes the RUNNING kernel touches per ray (its own node / leaf / triangle counters), which is an upper bound of what
-    # can reach HBM.  SURVEY 8(d)'s contract figure -- bytes the REFERENCE's binary traversal would touch for the same rays -- is kept as
-    # `contract_equivalent_GBps`: the 4-wide kernel reaches the same hits with half the visits, so that figure exceeds the peak and is
-    # a speed-up measure, not a bandwidth.
+    # `achieved` / `frac`: bytes that really cross the L2 <-> fabric boundary for this kernel (PMC capture of this workload AND these kernel
+    # sources) over the launch time measured live -- the north-star's own definition ("rocprof-reported HBM bandwidth in the traversal
+    # kernel").  Fabric-side: Infinity-Cache hits are included (the guide: FETCH_SIZE / the TCC_EA0 request counters cannot exclude them), so
+    # it is an UPPER bound of HBM proper.  Without a valid capture `achieved` and `frac` are null -- never a different quantity under the same
+    # name: the bytes the RUNNING kernel touches per ray (its own node / leaf / triangle counters, an upper bound of what can reach HBM)
+    # are `frac_own` only.  SURVEY 8(d)'s contract figure -- bytes the REFERENCE's binary traversal would touch for the same rays -- is kept
+    # as `contract_equivalent_GBps`: the 4-wide kernel reaches the same hits with half the visits, so that figure exceeds the peak and is a
+    # speed-up measure, not a bandwidth.
     if traffic and launch_s > 0:
         ach, src = traffic / launch_s / 1e9, "counters"
-    elif own_bytes and launch_s > 0:
-        ach, src = own_bytes / launch_s / 1e9, "own_bytes"
     else:
-        ach, src = achieved, "contract"
+        ach, src = None, None
     roofline = {"kernel": ("traceExtension (k_extend4: 4-wide quantised tree)" if not ctx.get_option("refill_extend") else "traceExtension (k_trace4r: 4-wide quantised tree, persistent waves with lane refill)") if args.extend_tree == 4 else "traceExtension (k_extend: binary tree)",
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "frac_source": src,
-                "definition": "achieved = fabric-side bytes of the extension kernel per launch (profiles/traffic_<workload>.json: rocprofv3 --pmc request counters by size, separate passes) / the kernel's average launch time measured live with HIP events on its stream inside the timed region (frac_source 'counters'); without a capture for this configuration, the bytes the running kernel itself touches per ray ('own_bytes').  launch_ms: as it runs in the timed region beside the concurrent shadow traversal; launch_ms_alone / frac_alone: same kernel, same steady state, serial schedule (untimed extra pass).",
-                "frac_alone": (ach * launch_s / alone_s / HBM_PEAK_GBS) if (alone_s > 0 and launch_s > 0) else None,
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
+                "frac_source": src, "traffic_capture_stale_keys": traffic_stale, "capture_key": key,
+                "definition": "achieved = fabric-side bytes (memory-side L2 requests; Infinity-Cache hits included = upper bound of HBM proper) of the extension kernel per launch (profiles/traffic_<workload>.json: rocprofv3 --pmc request counters by size, separate passes, captured on THIS configuration and THESE kernel sources: capture_key) / the kernel's average launch time measured live with HIP events on its stream inside the timed region.  null when no capture matches (traffic_capture_stale_keys says why); frac_own = bytes the running kernel itself touches per ray, an upper bound.  launch_ms: as it runs in the timed region beside the concurrent shadow traversal; launch_ms_alone / frac_alone: same kernel, same steady state, serial schedule (untimed extra pass).",
+                "frac_alone": (ach * launch_s / alone_s / HBM_PEAK_GBS) if (ach is not None and alone_s > 0 and launch_s > 0) else None,
                 "launch_ms": launch_s * 1e3, "launch_ms_alone": alone_s * 1e3,
                 "own_bytes_per_ray": own_bytes_per_ray,
                 "frac_own": (own_bytes / launch_s / 1e9 / HBM_PEAK_GBS) if (own_bytes and launch_s > 0) else None,
@@ -489,8 +521,10 @@ def main():
             "metric": "Mrays/s (primary+shadow) at 1080p, 8 bounces" if args.workload == "kitchen" else f"Mrays/s (primary+shadow), {args.workload}",
             "value": rays_total / elapsed / 1e6,
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_iterations": settle,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "windows": {"count": nwin, "headline": "median window", "Mrays_s": [float(x) for x in win_mrays], "ms_per_step": [float(e / args.steps * 1e3) for e in wins[:, 0]],
+                        "spread_pct": float((win_mrays.max() - win_mrays.min()) / win_mrays[med] * 100.0)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "

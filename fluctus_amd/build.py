@@ -71,15 +71,16 @@ def build_hip(force=False):
     return out
 
 
-def build_test_libs(force=False):
-    """Test infrastructure only: tests/fake_rccl.cpp (a librccl stand-in that moves tiles between host threads on one device, selected
-    with FLX_RCCL_LIB; lets the N > 1 branches of flx_gather run on a 1-GPU box)."""
-    src = [os.path.join(ROOT, "tests", "fake_rccl.cpp")]
-    out = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
-    if force or _stale(out, src):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        _run(["g++"] + CXX_FLAGS + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + src + ["-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
-    return out
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources libfluctus_hip.so is built from: csrc/*.hip, csrc/*.h, include/*.h (names + contents).
+    A PMC capture (profiles/traffic_<workload>.json) carries the hash of the kernels it was taken on; bench.py quotes it only while it matches."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) + _headers())
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_all(force=False):
@@ -90,6 +91,6 @@ def build_all(force=False):
     with open(os.path.join(PKG, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force), build_test_libs(force)]
+            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -210,6 +210,11 @@ static int settle(flx_ctx *c);
 static void flushExt(flx_ctx *c) { if (c->qs.extPend) { launch_bump_extension(c->stream, c->qs.counters, c->qs.extPend); c->qs.extPend = 0; } }
 const char *flx_last_error(flx_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+// refill = refillMin | waitMax << 8 (trace4r.hip).  refillMin 0 with a waitMax of 1..63 would end every descent round before a node is
+// visited (0 finished lanes >= refillMin) while no lane is idle for the refill to serve: the kernel would spin forever.  0 = the
+// thread-per-ray kernel; otherwise refillMin 1..64 and waitMax 0 (= 64) .. 64.
+static bool refill_value_ok(int v) { return v == 0 || (v > 0 && (v & 0xFF) >= 1 && (v & 0xFF) <= 64 && (v >> 8) <= 64); }
+
 int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
 {
     *out = nullptr;
@@ -220,9 +225,12 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if (num_tasks == 0) { g_create_error = "flx_create: num_tasks must be > 0"; return 1; }
     flx_ctx *c = new flx_ctx();
     c->device = device; c->numTasks = num_tasks;
-    // A/B hooks for whole test-suite runs: the defaults of the refill_extend / refill_shadow options
-    if (const char *e = getenv("FLX_REFILL_EXTEND")) c->refillExt = atoi(e);
-    if (const char *e = getenv("FLX_REFILL_SHADOW")) { c->refillShadowOpt = atoi(e); c->refillShadow = c->refillShadowOpt < 0 ? 0 : c->refillShadowOpt; }
+#ifdef FLX_LAB
+    // lab build only (scripts/build_variants.py, -DFLX_LAB): A/B hooks for whole test-suite runs -- the defaults of the refill_extend /
+    // refill_shadow options.  The shipped library reads no environment variable here.
+    if (const char *e = getenv("FLX_REFILL_EXTEND")) { const int v = atoi(e); if (refill_value_ok(v)) c->refillExt = v; }
+    if (const char *e = getenv("FLX_REFILL_SHADOW")) { const int v = atoi(e); if (v < 0 || refill_value_ok(v)) { c->refillShadowOpt = v; c->refillShadow = v < 0 ? 0 : v; } }
+#endif
     auto fail = [&](const char *what, hipError_t err) { g_create_error = std::string(what) + ": " + hipGetErrorString(err); flx_destroy(c); return 1; };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     // (stream priorities were tried: a high-priority shadow stream keeps the extension kernel at its undisturbed 0.86 ms and inflates
@@ -234,25 +242,12 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
     c->st.numTasks = num_tasks;
-#if STATE_LAYOUT
-    {   // three arrays of 64-byte lines (flx_device.h)
-        static const int group[S_NUM_REC][2] = {/*ORIG*/ {0, 0}, /*DIR*/ {0, 1}, /*HITP*/ {1, 0}, /*HITN*/ {1, 1}, /*HITUV*/ {1, 2}, /*THR*/ {0, 2},
-                                                /*EI*/ {0, 3}, /*SHO*/ {2, 0}, /*SHD*/ {2, 1}, /*LBSDF*/ {2, 2}, /*LEMIT*/ {2, 3}, /*LT*/ {1, 3}};
-        float4 *line[3];
-        for (int g = 0; g < 3; g++) {
-            if (dalloc(c, c->fixedAllocs, &line[g], N * 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
-            (void)hipMemsetAsync(line[g], 0, N * 4 * sizeof(float4), c->stream);
-        }
-        for (int r = 0; r < S_NUM_REC; r++) c->st.rec[r] = line[group[r][0]] + group[r][1];
-    }
-#else
     // (staggering the twelve arrays inside their allocations -- 272 / 4112 / 65808 elements per array -- changes nothing: the fused pass lands on
     //  one of three levels, 0.457 / 0.479 / 0.507 ms, from one process to the next with or without it, and so does ONE allocation for all twelve; profiles/r03_state_stagger_ab.txt, r03_state_slab_ab.txt)
     for (int r = 0; r < S_NUM_REC; r++) {
         if (dalloc(c, c->fixedAllocs, &c->st.rec[r], N)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
         (void)hipMemsetAsync(c->st.rec[r], 0, N * sizeof(float4), c->stream);
     }
-#endif
     if (dalloc(c, c->fixedAllocs, &c->st.phase, N) || dalloc(c, c->fixedAllocs, &c->mkStats, 4)) return fail("hipMalloc(state)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->st.phase, 0, N * 4, c->stream); (void)hipMemsetAsync(c->mkStats, 0, 16, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->st.blocked, N) || dalloc(c, c->fixedAllocs, &c->st.pickProb, N) || dalloc(c, c->fixedAllocs, &c->st.firstDiffuse, N))
@@ -788,6 +783,10 @@ int flx_clear_queues(flx_ctx *c)
     c->qs.extPend = 0; c->matQueuesEmpty = true;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
+    if (c->cursorDirty[0] || c->cursorDirty[1]) {       // the block cursors of the persistent traversal kernels go with the counters
+        HIPCHK(c, hipMemsetAsync(c->qs.cursors, 0, 4 * FLX_NUM_BLOCK_CURSORS * FLX_CURSOR_STRIDE, c->stream));
+        c->cursorDirty[0] = c->cursorDirty[1] = false;
+    }
     return 0;
 }
 
@@ -914,14 +913,21 @@ struct Rccl {
     std::string err;
 };
 Rccl g_rccl;
+// TEST HOOK: FLX_RCCL_LIB is honoured only together with FLX_ALLOW_RCCL_OVERRIDE=1, so that a stray variable in a production
+// environment cannot make the library dlopen an arbitrary path or change which gather path a local group takes.
+const char *rccl_override()
+{
+    const char *over = getenv("FLX_RCCL_LIB"), *allow = getenv("FLX_ALLOW_RCCL_OVERRIDE");
+    return (over && *over && allow && strcmp(allow, "1") == 0) ? over : nullptr;
+}
 bool rccl_load()
 {
     if (g_rccl.dl) return true;
-    // FLX_RCCL_LIB=<path>: bind another library with the same entry points (tests/fake_rccl.cpp moves the tiles between host threads
-    // on ONE device, so that the N > 1 send / receive code below runs on a 1-GPU box; never set in production)
+    // FLX_RCCL_LIB=<path> + FLX_ALLOW_RCCL_OVERRIDE=1: bind another library with the same entry points (tests/fake_rccl.cpp moves the tiles
+    // between host threads on ONE device, so that the N > 1 send / receive code below runs on a 1-GPU box; never set in production)
     void *dl = nullptr;
-    const char *over = getenv("FLX_RCCL_LIB");
-    if (over && *over) {
+    const char *over = rccl_override();
+    if (over) {
         dl = dlopen(over, RTLD_NOW | RTLD_LOCAL);
         if (!dl) { g_rccl.err = std::string("FLX_RCCL_LIB=") + over + " not loadable: " + dlerror(); return false; }
     }
@@ -1014,7 +1020,7 @@ int flx_group_init_local(flx_ctx **ctxs, uint32_t n)
     for (uint32_t i = 0; i < n; i++) { NEED(c0, ctxs[i], "flx_group_init_local: null context"); for (uint32_t j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false; }
     for (uint32_t i = 0; i < n; i++) { MUTATES(ctxs[i]); flx_group_destroy(ctxs[i]); }
     // (with a stand-in transport bound through FLX_RCCL_LIB the communicator path is taken whatever the devices are: tests)
-    { const char *over = getenv("FLX_RCCL_LIB"); if (over && *over) distinct = true; }
+    if (rccl_override()) distinct = true;
     if (distinct) {
         NEED(c0, rccl_load(), g_rccl.err);
         std::vector<ncclComm_t> comms(n); std::vector<int> devs(n);
@@ -1234,8 +1240,9 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
         return 0;
     }
-    if (name && strcmp(name, "refill_extend") == 0 && value >= 0 && (value & 0xFF) <= 64 && (value >> 8) <= 64) { MUTATES(c); c->refillExt = value; return 0; }
-    if (name && strcmp(name, "refill_shadow") == 0 && value >= -1 && (value < 0 || ((value & 0xFF) <= 64 && (value >> 8) <= 64))) { MUTATES(c); c->refillShadowOpt = value; pickSchedule(c); return 0; }
+    if (name && strcmp(name, "refill_extend") == 0 && refill_value_ok(value)) { MUTATES(c); c->refillExt = value; return 0; }
+    if (name && strcmp(name, "refill_shadow") == 0 && (value == -1 || refill_value_ok(value))) { MUTATES(c); c->refillShadowOpt = value; pickSchedule(c); return 0; }
+    if (name && (strcmp(name, "refill_extend") == 0 || strcmp(name, "refill_shadow") == 0)) { c->err = "flx_set_option: refill value must be 0 or refillMin (1..64) | waitMax (0..64) << 8"; return 1; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");

@@ -32,18 +32,10 @@ using namespace flx;
 
 enum { S_ORIG = 0, S_DIR, S_HITP, S_HITN, S_HITUV, S_THR, S_EI, S_SHO, S_SHD, S_LBSDF, S_LEMIT, S_LT, S_NUM_REC };
 
-// STATE_LAYOUT 0: twelve separate arrays (pure SoA of float4).  1: three arrays of 64-byte LINES, four records each --
-//   A {ORIG, DIR, THR, EI}  B {HITP, HITN, HITUV, LT}  C {SHO, SHD, LBSDF, LEMIT}
-// -- so that the kernels that reach the state through a queue (raygen, materials, both traversals) touch one line per
-// group instead of one line per record.  Record r of path gid is rec[r][gid * STATE_STRIDE] in both layouts.
-#ifndef STATE_LAYOUT
-#define STATE_LAYOUT 0
-#endif
-#define STATE_STRIDE (STATE_LAYOUT ? 4 : 1)
-
 struct State {
-    float4 *rec[S_NUM_REC];       // record r of path gid: rec[r] + gid * STATE_STRIDE
-    __host__ __device__ __forceinline__ float4 *at(int r, uint32_t gid) const { return rec[r] + (size_t)gid * STATE_STRIDE; }
+    float4 *rec[S_NUM_REC];       // record r of path gid: rec[r] + gid  (pure SoA of float4; a layout of 64-byte lines with four records each
+                                  // was measured in round 1 and lost: the coalesced kernels turn into 16-byte accesses at a 64-byte stride)
+    __host__ __device__ __forceinline__ float4 *at(int r, uint32_t gid) const { return rec[r] + (size_t)gid; }
     uint32_t *blocked;            // shadowRayBlocked
     float *pickProb;              // lastLightPickProb
     uint32_t *firstDiffuse;       // carried for export parity only
@@ -53,8 +45,9 @@ struct State {
 
 // Block cursors of the persistent traversal kernels (trace4r.hip): one per XCD and kernel, [0..7] closest hit, [8..15] any hit, FLX_CURSOR_STRIDE
 // words apart (every cursor is a hot atomic: each gets a cache line and L2 channel of its own).  A wave takes its next 64-ray block from the list of
-// its own XCD (blocks x, x + 8, x + 16, ...) and from the next XCD's list when its own is exhausted.  Zeroed wherever the queue counters are
-// (flx_clear_queues, k_end_iteration).
+// its own XCD (blocks x, x + 8, x + 16, ...) and from the next XCD's list when its own is exhausted.  A persistent launch needs them at zero:
+// k_end_iteration zeroes them with the counters, flx_clear_queues does when a launch used them since (flx_ctx::cursorDirty), and the
+// launch sites (flx_wf_extend / flx_wf_shadow) zero them first whenever cursorDirty says neither happened in between.
 #define FLX_NUM_BLOCK_CURSORS 16
 #define FLX_CURSOR_STRIDE 64
 

@@ -184,8 +184,12 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
         cached = n;
     }
     int perCU = cached;
-    { static const char *e = getenv("FLX_PERSISTENT_WAVES_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }      // A/B hook: leave wave slots to a concurrent kernel
+#ifdef FLX_LAB      // lab build only (-DFLX_LAB): A/B hooks that leave wave slots to a concurrent kernel (profiles/r03_slot_split_ab.txt)
+    { static const char *e = getenv("FLX_PERSISTENT_WAVES_PER_CU"); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }
     if (capEnv) { const char *e = getenv(capEnv); if (e && atoi(e) > 0 && atoi(e) < perCU) perCU = atoi(e); }                          // (per kernel family)
+#else
+    (void)capEnv;
+#endif
     const uint32_t g = numCUs * (uint32_t)perCU;
     const uint32_t blocks = (numTasks + 63u) / 64u;
     return g < blocks ? g : blocks;
@@ -194,7 +198,7 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
 // refill = refillMin | waitMax << 8.  Leaves RAW hit records behind (the caller remembers: api.hip, flx_ctx::rawHits).
 void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor)
 {
-    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
+    const int refillMin = (refill & 0xFF) ? (refill & 0xFF) : 1, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;      // (refillMin 0 would spin: api.hip, refill_value_ok)
     static int occ = 0;
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
     const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_EXT");
@@ -208,7 +212,7 @@ void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const f
 
 void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor)
 {
-    const int refillMin = refill & 0xFF, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
+    const int refillMin = (refill & 0xFF) ? (refill & 0xFF) : 1, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;
     static int occ[2] = {0, 0};
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
     // visit order of the any-hit traversal (trace4.hip: launch_shadow4): far -> near when every shadow ray runs toward the environment light

@@ -211,7 +211,7 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     material queues empty (flx_clear_queues / flx_end_iteration_async since the last logic) and wfSeparateQueues
  *                     (or a build that inlines every type) -- otherwise, and with 0, every call launches its own kernels at once
  *   fuse_set          BSDF types the fused pass inlines: 1 diffuse only | 31 all six.  flx_upload_scene picks it from the scene
- *                     (diffuse surfaces >= half of the triangle area: 1, else 31); set it after the upload to override
+ *                     (diffuse surfaces >= 3/4 of the triangle area: 1, else 31); set it after the upload to override
  *   ext_order         how the fused pass lists the continuing paths in the extension queue: 0 one segment per material queue, in the
  *                     separate kernels' order | 1 all of them by path id (the same SET of paths either way; the reference's order is
  *                     whatever its atomic_inc produces).  flx_upload_scene picks it with fuse_set (1 with 31); set it afterwards to override

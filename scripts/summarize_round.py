@@ -1,5 +1,6 @@
-"""Summarise a scripts/profile_r03.sh capture into profiles/r03_<workload>_{kernel_stats.csv,counters.txt} and profiles/traffic_<workload>.json
-(the file bench.py reads for roofline.traffic / frac)."""
+"""Summarise a scripts/profile_round.sh capture into profiles/<tag>_<workload>_{kernel_stats.csv,counters.txt} and profiles/traffic_<workload>.json
+(the file bench.py reads for roofline.traffic / frac; it carries the bench line's `capture_key` incl. the hash of the kernel sources, and
+bench.py refuses it as soon as any key differs)."""
 import collections
 import csv
 import glob
@@ -8,27 +9,35 @@ import os
 import shutil
 import sys
 
-out, wl, extra = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+out, tag, wl, extra = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] if len(sys.argv) > 4 else "")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(prof, f"r03_{wl}_kernel_stats.csv"))
+    shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
 KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
         "k_queue_scatter", "k_queue_scan")
+# Steady state only: the first `settle_iterations` dispatches of every kernel are the transient from reset (iteration 0 traces nothing but
+# primary rays) and are dropped; what is averaged is the timed window + the extra untimed passes over the same steady state.
+skip = int(bench.get("settle_iterations", 0))
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
+    rows = collections.defaultdict(list)              # (key, counter) -> [(dispatch id, value)]
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         for key in KEYS:
             if key in k:
-                a = acc[key][r["Counter_Name"]]
-                a[0] += float(r["Counter_Value"]); a[1] += 1
+                rows[(key, r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 break
+    for (key, cn), lst in rows.items():
+        lst.sort()
+        lst = lst[skip:] if len(lst) > 2 * skip else lst
+        a = acc[key][cn]
+        a[0] += sum(v for _, v in lst); a[1] += len(lst)
 lines = []
 traffic = {}
 for k in sorted(acc):
     v = {c: a[0] / a[1] for c, a in acc[k].items()}
-    lines.append(f"== {k}   (averages per dispatch, {max(a[1] for a in acc[k].values())} dispatches)")
+    lines.append(f"== {k}   (averages per dispatch, {max(a[1] for a in acc[k].values())} steady-state dispatches; the first {skip} of the process dropped)")
     for c in sorted(v):
         lines.append("   %-28s %.6g" % (c, v[c]))
     rd, r32, r64, r128 = (v.get("TCC_EA0_RDREQ_sum", 0), v.get("TCC_EA0_RDREQ_32B_sum", 0), v.get("TCC_EA0_RDREQ_64B_sum", 0), v.get("TCC_EA0_RDREQ_128B_sum", 0))
@@ -43,19 +52,15 @@ for k in sorted(acc):
                       "write_requests_64B": w64, "write_requests_32B": wr - w64, "fetch_size_kib": v.get("FETCH_SIZE"), "write_size_kib": v.get("WRITE_SIZE")}
     if v.get("SQ_INSTS_VALU"):
         lines.append("   lanes active per VALU instruction %.1f of 64" % (v.get("SQ_THREAD_CYCLES_VALU", 0) / v["SQ_INSTS_VALU"]))
-open(os.path.join(prof, f"r03_{wl}_counters.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(prof, f"{tag}_{wl}_counters.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-bench = {}
-try:
-    bench = json.loads(open(os.path.join(prof, f"r03_{wl}_bench.json")).readline())
-except Exception:
-    pass
 ext = next((k for k in ("k_trace4r<false", "k_extend4<false>", "k_extend<false>") if k in traffic), None)
 if ext:
     cfg = bench.get("config", {})
     t = traffic[ext]
     extra_k = {k: traffic[k]["read_bytes"] + traffic[k]["write_bytes"] for k in ("k_commit4", "k_lightfix4") if k in traffic}
-    j = {"source": f"scripts/profile_r03.sh {wl} {extra}".strip() + " -> profiles/r03_%s_counters.txt (rocprofv3 --pmc, separate passes with --kernel-trace only)" % wl,
+    j = {"source": f"scripts/profile_round.sh {tag} {wl} {extra}".strip() + " -> profiles/%s_%s_counters.txt (rocprofv3 --pmc, separate passes with --kernel-trace only)" % (tag, wl),
+         "capture_key": (bench.get("roofline") or {}).get("capture_key"),
          "kernel": ext, "workload": wl, "extend_tree": 4 if "4" in ext else 2, "num_tasks": cfg.get("num_tasks_per_gpu"), "refill_extend": cfg.get("refill_extend", 0),
          "extend_read_requests_128B": t["read_requests_128B"], "extend_read_requests_64B": t["read_requests_64B"], "extend_write_requests_64B": t["write_requests_64B"],
          "extend_write_requests_32B": t["write_requests_32B"], "fetch_size_kib": t["fetch_size_kib"], "write_size_kib": t["write_size_kib"],

@@ -17,3 +17,20 @@ def _built():
     """Build the CPU-side libraries once (host lib, oracle, C-ABI library) if they are missing."""
     import __graft_entry__ as g
     g.build_cpu_libs()
+    build_fake_rccl()
+
+
+def build_fake_rccl(force=False):
+    """Test infrastructure only (not part of the product build): tests/fake_rccl.cpp -> tests/_build/libfake_rccl.so, a librccl stand-in that
+    moves tiles between host threads on one device (tests/test_gpu_rccl_fake.py; selected with FLX_RCCL_LIB + FLX_ALLOW_RCCL_OVERRIDE=1)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    out = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    if not os.path.isdir("/opt/rocm/include"):
+        return None
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-pthread"], check=True)
+    return out

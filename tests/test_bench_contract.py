@@ -27,8 +27,16 @@ def test_bench_json_line_contract(tmp_path):
     r = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["traffic"] is None                                   # the PMC capture belongs to the default configuration only
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # the committed PMC capture belongs to the default configuration (and to the kernel sources it was taken on): here it must be
+    # refused, and then `achieved` / `frac` are null -- never another quantity under the same name (frac_own carries the upper bound)
+    assert r["traffic"] is None and r["achieved"] is None and r["frac"] is None and r["frac_source"] is None
+    assert r["traffic_capture_stale_keys"] and "num_tasks" in r["traffic_capture_stale_keys"]
+    assert 0.0 < r["frac_own"] < 1.5
+    # protocol: settle >= 2 * maxBounces + 2 whatever --warmup says, five windows, headline = the median one
+    assert j["settle_iterations"] >= 2 * j["config"]["max_bounces"] + 2 and j["settle_iterations"] >= j["warmup"]
+    w = j["windows"]
+    assert w["count"] == 5 and len(w["Mrays_s"]) == 5 and sorted(w["Mrays_s"])[2] == pytest.approx(j["value"], rel=1e-9)
     assert "extend" in j["kernel_ms_avg_source"]["timed_region"]    # the roofline kernel is event-timed inside the timed region
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

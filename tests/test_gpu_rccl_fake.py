@@ -18,8 +18,8 @@ FAKE = os.path.join(ROOT, "tests", "_build", "libfake_rccl.so")
 
 
 def _run(n, root, mode, timeout=300, **extra):
-    assert os.path.exists(FAKE), "tests/_build/libfake_rccl.so missing: run __graft_entry__.build()"
-    env = dict(os.environ, FLX_RCCL_LIB=FAKE, FLX_NO_BUILD="1", **{k: str(v) for k, v in extra.items()})
+    assert os.path.exists(FAKE), "tests/_build/libfake_rccl.so missing (tests/conftest.py: build_fake_rccl)"
+    env = dict(os.environ, FLX_RCCL_LIB=FAKE, FLX_ALLOW_RCCL_OVERRIDE="1", FLX_NO_BUILD="1", **{k: str(v) for k, v in extra.items()})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_fake_driver.py"), str(n), str(root), mode],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -77,7 +77,7 @@ def test_bench_exits_nonzero_when_the_native_gather_fails(tmp_path):
     """bench.py as the driver launches it for N > 1 (one rank here, FLX_FORCE_DIST=1) with a transport whose communicator cannot be
     formed: the JSON line still comes out, carries the error, and the exit status is not 0."""
     env = dict(os.environ, FLX_FORCE_DIST="1", FLX_BENCH_TRIS="30000", FLX_BVH_CACHE=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0",
-               FLX_RCCL_LIB=FAKE, FAKE_RCCL_BREAK="4", FLX_NO_BUILD="1")
+               FLX_RCCL_LIB=FAKE, FLX_ALLOW_RCCL_OVERRIDE="1", FAKE_RCCL_BREAK="4", FLX_NO_BUILD="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--width", "320",
            "--height", "180", "--num-tasks", "65536", "--no-cpu-baseline"]
