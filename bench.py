@@ -46,7 +46,14 @@ WORKLOADS = {
     # (round 1 had to use the binned builder here: the serial SBVH build of 8.9 M triangles takes ~10 min; the parallel one ~1 min)
     "courtyard-1440p": ("courtyard", 10000000, 44, "sbvh", 2560, 1440, 12, 1, 0, (0.0, 3.0, 17.0), (0.0, 2.0, 0.0)),
     "courtyard-2160p": ("courtyard", 10000000, 44, "sbvh", 3840, 2160, 16, 1, 0, (0.0, 3.0, 17.0), (0.0, 2.0, 0.0)),
+    # A REAL reference asset under the reference's own benchmark protocol: assets/egyptcat/egyptcat.obj is scene #1 of Tracer::runBenchmark
+    # (src/tracer.cpp:384-389), rendered at 1024 x 1024 (:365-366) with the start-up parameters (:38-52, :760-797: default camera and area
+    # light, no environment map, 10 bounces, ONE material queue) and the default wfBufferSize of 2^20 paths (src/settings.cpp:20; pass
+    # --num-tasks 1048576 for the literal protocol).  The scene travels as data: tests/golden/egyptcat_scene.npz, written by
+    # scripts/make_egyptcat_fixture.py from the OBJ / MTL / PNG through host/scene.cpp (/root/reference does not exist on the GPU box).
+    "egyptcat": ("fixture:egyptcat_scene.npz", 16040, 0, "sbvh", 1024, 1024, 10, 0, 1, (0.0, 1.0, 3.5), (0.0, 1.0, 2.5)),
 }
+SINGLE_MATERIAL_QUEUE = {"egyptcat"}        # workloads that keep the reference's default wfSeparateQueues = 0
 
 
 def build_workload(width=None, height=None, name="kitchen"):
@@ -54,11 +61,17 @@ def build_workload(width=None, height=None, name="kitchen"):
     gen, tris, seed, bvh, w, h, bounces, use_env, use_area, cam, target = WORKLOADS[name]
     width, height = width or w, height or h
     tris = int(os.environ.get("FLX_BENCH_TRIS", tris))          # experiments only (scripts/sweep.sh); the bench line uses the default
-    d = host.generate_scene(gen, tris, seed)
+    if gen.startswith("fixture:"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", gen[len("fixture:"):]))
+        d = host.SceneData()
+        d.tris = z["tris"].view(wire.TRIANGLE).reshape(-1); d.materials = z["materials"].view(wire.MATERIAL).reshape(-1)
+        d.texdesc = z["texdesc"].view(wire.TEXDESC).reshape(-1); d.texdata = z["texdata"]
+    else:
+        d = host.generate_scene(gen, tris, seed)
     # hierarchy cache (the reference's on-disk format, host/bvh.hpp) so that the back-to-back N = 1, 2, 4, 8 runs and the N ranks of
     # one run do not each spend 10-40 s in the SBVH builder; written atomically, keyed by the generator arguments
     cache_dir = os.environ.get("FLX_BVH_CACHE", "/tmp/flx_bvh_cache")
-    cache = os.path.join(cache_dir, f"hierarchy_{gen}_{tris}_{seed}_{bvh}_{d.tris.size}.bin")
+    cache = os.path.join(cache_dir, f"hierarchy_{gen.replace(':', '_')}_{tris}_{seed}_{bvh}_{d.tris.size}.bin")
     loaded = False
     if cache_dir and os.path.exists(cache):
         try:
@@ -79,7 +92,7 @@ def build_workload(width=None, height=None, name="kitchen"):
                 pass
     p = wire.default_params(width, height, d.world_radius, d.tris.size)
     wire.look_at(p, cam, target, fov=60.0)
-    p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = bounces, use_env, use_area, 1
+    p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = bounces, use_env, use_area, (0 if name in SINGLE_MATERIAL_QUEUE else 1)
     env = host.synthetic_sky(512, 256)
     return d, p, env
 
@@ -528,7 +541,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
-                                    "separate material queues") if args.workload == "kitchen" else args.workload + "-proc",
+                                    "separate material queues") if args.workload == "kitchen" else
+                                   ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
                        "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
                        "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),

@@ -54,10 +54,14 @@ def teapot():
     print("teapot_wf.npz", cnts[-1])
 
 
-def steps(tag, denoiser=False, **flags):
-    d = common.mixed_material_scene()
-    w, h, n = 48, 32, 1024
-    p = common.scene_params(d, w, h, maxBounces=5, envMapStrength=1.5, **flags)
+def steps(tag, denoiser=False, scene=None, scene_file=None, w=48, h=32, n=1024, params=None, **flags):
+    """scene / scene_file: another scene than the all-BSDF test scene, its triangle / material / texture arrays kept in a fixture of their
+    own (tests/golden/<scene_file>) instead of being stored again; params "reference": the reference's start-up parameters untouched."""
+    d = scene if scene is not None else common.mixed_material_scene()
+    if params == "reference":
+        p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    else:
+        p = common.scene_params(d, w, h, maxBounces=5, envMapStrength=1.5, **flags)
     e = host.synthetic_sky(64, 32)
     c = RefContext(n)
     if denoiser:
@@ -84,7 +88,8 @@ def steps(tag, denoiser=False, **flags):
                         names=np.array(names), states=np.stack([s["state"] for s in snaps]),
                         counters=np.stack([s["counters"] for s in snaps]), queues=np.stack([s["queues"] for s in snaps]),
                         env_rgb=e.rgb, env_prob=e.prob, env_alias=e.alias, env_pdf=e.pdf, env_wh=np.array([e.w, e.h]),
-                        pixel_cursor=np.array(cursors, np.uint32), **scene_arrays(d))      # cursor in effect when snapshot k was taken
+                        pixel_cursor=np.array(cursors, np.uint32),                         # cursor in effect when snapshot k was taken
+                        **(dict(scene_file=np.array(scene_file), nodes=d.nodes.view(np.uint8).reshape(-1), indices=d.indices) if scene_file else scene_arrays(d)))
     print(f"steps_{tag}.npz", names)
 
 

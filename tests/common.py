@@ -137,6 +137,29 @@ def scene_params(d, w, h, **kw):
     return p
 
 
+def fixture_scene(z):
+    """SceneData of a golden fixture: its own arrays, or -- `scene_file` -- the triangle / material / texture arrays of another fixture
+    (tests/golden/egyptcat_scene.npz) with the fixture's own BVH."""
+    s = np.load(os.path.join(GOLDEN, str(z["scene_file"]))) if "scene_file" in z.files else z
+    d = host.SceneData()
+    d.tris = s["tris"].view(wire.TRIANGLE).reshape(-1)
+    d.materials = s["materials"].view(wire.MATERIAL).reshape(-1)
+    d.texdesc = s["texdesc"].view(wire.TEXDESC).reshape(-1) if s["texdesc"].size else np.zeros(0, wire.TEXDESC)
+    d.texdata = s["texdata"]
+    if "nodes" in z.files:
+        d.nodes = z["nodes"].view(wire.NODE).reshape(-1)
+        d.indices = z["indices"]
+    return d
+
+
+def egyptcat_scene():
+    """tests/golden/egyptcat_scene.npz (scripts/make_egyptcat_fixture.py): the reference's assets/egyptcat/egyptcat.obj as loaded by
+    host/scene.cpp, with the SBVH built here."""
+    d = fixture_scene(np.load(os.path.join(GOLDEN, "egyptcat_scene.npz")))
+    host.build_bvh(d, "sbvh")
+    return d
+
+
 def sync(dst, src):
     """Make dst's path state / queues / counters identical to src's."""
     dst.state_import(src.state_export())
@@ -149,9 +172,20 @@ def sync(dst, src):
     dst.set_counters(cnt)
 
 
-def state_diff(sa, sb, rtol, atol, skip_cols=(), mask=None):
-    """Compare two (64, N) reference-layout states. Integer columns exact, float columns within tol.
-    Returns a list of human-readable failures."""
+def sharp_lobe_paths(d, state):
+    """Paths whose hit material is a glossy / GGX lobe with Ns >= 1e4 (alpha = sqrt(2 / (2 + Ns)) <= 0.014; egyptcat.mtl: Ns 100000).
+    The GGX density D = a^2 / (pi ((n.h)^2 (a^2 - 1) + 1)^2) is evaluated at n.h = 1 - O(a^2): one ulp of cos(theta) (6e-8) against
+    a^2 = 2e-5 moves the denominator by ~1 %, so the REFERENCE's libm build and the oracle's flx_math can differ by that much in the pdf of a
+    sampled direction there (observed: 0.5 % on one path of 4 096) -- the quantity is ill-conditioned in fp32, in the reference itself.
+    Device vs oracle stays bit-exact (same flx_math)."""
+    mid = np.clip(state.view(np.int32)[COL.MAT_ID], 0, d.materials.size - 1)
+    m = d.materials[mid]
+    return (m["Ns"] >= 1.0e4) & np.isin(m["type"], (BXDF.GLOSSY, BXDF.GGX_ROUGH_REFLECTION, BXDF.GGX_ROUGH_DIELECTRIC))
+
+
+def state_diff(sa, sb, rtol, atol, skip_cols=(), mask=None, col_rtol=None):
+    """Compare two (64, N) reference-layout states. Integer columns exact, float columns within tol (col_rtol: {column: per-path
+    rtol array or scalar} overrides).  Returns a list of human-readable failures."""
     fails = []
     ia, ib = sa.view(np.uint32), sb.view(np.uint32)
     for c in range(64):
@@ -163,8 +197,13 @@ def state_diff(sa, sb, rtol, atol, skip_cols=(), mask=None):
         if c in INT_COLS:
             bad = a != b
         else:
+            rt = rtol
+            if col_rtol is not None and c in col_rtol:
+                rt = np.asarray(col_rtol[c])
+                if rt.ndim and mask is not None:
+                    rt = rt[mask]
             with np.errstate(all="ignore"):
-                bad = ~(np.abs(a - b) <= atol + rtol * np.abs(b))
+                bad = ~(np.abs(a - b) <= atol + rt * np.abs(b))
             bad &= ~((a == b) | (np.isnan(a) & np.isnan(b)))
         if bad.any():
             j = int(np.argmax(bad))

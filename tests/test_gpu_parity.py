@@ -482,7 +482,7 @@ def test_single_leaf_scene_and_deep_stack_spill():
     _free_run(g, o, 32 * 32, 6)
 
 
-@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr", "denoiser_env_area_sep"])
+@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr", "denoiser_env_area_sep", "egyptcat"])
 def test_device_vs_reference_kernel_outputs(tag):
     """The HIP path directly against the REFERENCE kernels' own outputs (tests/golden/steps_*.npz, produced by
     oracle/_ref): every kernel of two iterations, from the reference's input state.  Integers exact, floats within the
@@ -495,10 +495,7 @@ def test_device_vs_reference_kernel_outputs(tag):
     z = np.load(path)
     n = int(z["num_tasks"])
     p = z["params"].view(wire.RENDER_PARAMS).reshape(())
-    d = host.SceneData()
-    d.tris = z["tris"].view(wire.TRIANGLE).reshape(-1); d.nodes = z["nodes"].view(wire.NODE).reshape(-1); d.indices = z["indices"]
-    d.materials = z["materials"].view(wire.MATERIAL).reshape(-1)
-    d.texdesc = z["texdesc"].view(wire.TEXDESC).reshape(-1); d.texdata = z["texdata"]
+    d = common.fixture_scene(z)
     e = host.EnvMap(int(z["env_wh"][0]), int(z["env_wh"][1]), z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])
     g = HipContext(n)
     g.set_option("extend_tree", TRACE_MODE["ext"]); g.set_option("shadow_tree", TRACE_MODE["shadow"])
@@ -537,5 +534,6 @@ def test_device_vs_reference_kernel_outputs(tag):
         mask = None
         if names[k] == "materials":
             mask = ~((sa[COL.T] == 0) & (sa[COL.T + 1] == 0) & (sa[COL.T + 2] == 0))
-        fails = common.state_diff(sa, sb, 1e-3 if names[k] == "materials" else 1e-4, 1e-5, mask=mask)
+        col_rtol = {COL.LAST_PDF_W: np.where(common.sharp_lobe_paths(d, sb), 2e-2, 1e-3)} if names[k] == "materials" else None      # (ill-conditioned in the reference itself: common.sharp_lobe_paths)
+        fails = common.state_diff(sa, sb, 1e-3 if names[k] == "materials" else 1e-4, 1e-5, mask=mask, col_rtol=col_rtol)
         assert not fails, f"step {k} {names[k]}: " + "; ".join(fails[:4])

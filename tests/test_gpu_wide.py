@@ -28,7 +28,7 @@ HIT_COLS = [COL.P, COL.P + 1, COL.P + 2, COL.N, COL.N + 1, COL.N + 2, COL.UV, CO
 def _report(name, payload):
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r03_wide_flips.json")
+    path = os.path.join(out_dir, "r04_wide_flips.json")
     try:
         j = json.load(open(path))
     except Exception:
@@ -318,6 +318,29 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
+def test_default_path_4M_checkpoint_vs_oracle():
+    """The bench's OWN path count: every other device-vs-ORACLE run is 1 M paths, bench.py times 4 M (other grid sizes, cursor traffic,
+    persistent-grid : block ratio).  kitchen at n = 1 << 22: the device runs 20 iterations alone (stationary queue mix, deep paths in
+    flight), then two whole iterations in lockstep with the oracle, ray by ray as above."""
+    n = 1 << 22
+    rays, flips = _free_run_default_vs_oracle("kitchen", n, 2, start_iterations=20)
+    _report("default_4M_checkpoint_kitchen", {"paths": n, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips})
+    assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
+
+
+def test_egyptcat_reference_protocol_free_run_vs_oracle():
+    """A REAL reference asset under the reference's own benchmark protocol: assets/egyptcat/egyptcat.obj (scene #1 of Tracer::runBenchmark,
+    src/tracer.cpp:384-389; here from tests/golden/egyptcat_scene.npz) at 1024 x 1024 (:365-366) with the start-up parameters (default
+    camera and area light, 10 bounces, single material queue) and the default wfBufferSize of 2^20 paths: 10 whole iterations of the
+    shipped default path beside the ORACLE, the same assertions as test_default_path_free_run_vs_oracle_full_size."""
+    n = 1 << 20
+    rays, flips = _free_run_default_vs_oracle("egyptcat", n, 10)
+    _report("default_free_run_egyptcat", {"paths": n, "iterations": 10, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips,
+                                          "flip_rate": flips / max(1, rays)})
+    assert rays > 5 * n                              # (rays that leave the scene terminate: fewer than n per iteration after the first)
+    assert flips <= FLIP_BUDGET * rays, (rays, flips)
+
+
 @pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
 def test_bench_launch_chain_vs_oracle_full_size(workload):
     """The launch chain bench.py times, untouched: logic -> genRays -> materials -> extension -> shadow -> clear, nothing looking at the
@@ -339,8 +362,54 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
     assert g.get_option("refill_extend") > 0 and g.get_option("fuse") == 1 and g.get_option("extend_tree") == 4
     rays = ext_rays = forked = 0
     skip = np.zeros(64, bool); skip[list(common.PAD_COLS)] = True; skip[COL.PHASE] = True
+    cursor = 0                                            # the host-side pixel cursor both contexts carry (replayed from the oracle's counts)
+    common_state = [None, 0, 0]                           # oracle state, cursor, iteration count at the last point both sides were identical
+    explained = []
 
-    def checkpoint(what):
+    def explain_forks(bad_paths, upto, what):
+        """A path whose state differs at a checkpoint must have been forked by a TIE: replay the stretch since the last common state on
+        both sides, this time looking after every extension launch (the pattern of _free_run_default_vs_oracle), and demand that every
+        differing path shows, at the launch where it first differs, hit records that differ in `i` but agree in `t` to 1e-5 -- anything
+        else (a wrong commit in the fused RAW pass, a wrong traversal result) has no such launch and fails here.  The device's traversal
+        is deterministic per ray, so the replay reproduces the flip."""
+        s0, cur0, it0 = common_state
+        assert s0 is not None
+        s1 = o.state_export()                             # where the main loop continues afterwards
+        for c in (g, o):
+            c.state_import(s0); c.pixel_index_reset(); c.pixel_index_update(npix, cur0)
+        tied = set()
+        cur = cur0
+        for j in range(it0, upto):
+            for c in (g, o):
+                c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+            cgj, coj = g.get_counters(), o.get_counters(); g.finish()
+            cgj, coj = np.array(cgj, copy=True), np.array(coj, copy=True)
+            assert (cgj == coj).all(), f"{workload} {what}: replay it{j}: counters {cgj} vs {coj}"
+            qo = o.queue_read(Q.EXTENSION)[:int(coj[Q.EXTENSION])]
+            g.wf_extend(); o.wf_extend(); g.finish()
+            sg, so = g.state_export(), o.state_export()
+            flip = np.zeros(sg.shape[1], bool)
+            flip[qo] = sg.view(np.uint32)[COL.HIT_I][qo] != so.view(np.uint32)[COL.HIT_I][qo]
+            fails = common.state_diff(sg, so, 0.0, 0.0, mask=~flip)
+            assert not fails, f"{workload} {what}: replay it{j} after extend, beyond hit-index flips: " + "; ".join(fails[:4])
+            if flip.any():
+                fr = np.nonzero(flip)[0]
+                assert np.allclose(sg[COL.HIT_T][fr], so[COL.HIT_T][fr], rtol=1e-5, atol=1e-6), f"{workload} {what}: replay it{j}: a flip that is not a tie in t"
+                tied.update(int(x) for x in fr)
+                g.state_import(so)
+            g.wf_shadow(); o.wf_shadow()
+            for c in (g, o):
+                c.clear_queues(); c.finish(); c.pixel_index_update(npix, int(coj[Q.RAYGEN]))
+            cur = (cur + int(coj[Q.RAYGEN])) % npix
+        unexplained = sorted(set(int(x) for x in bad_paths) - tied)
+        assert not unexplained, f"{workload} {what}: paths {unexplained[:8]} differ from the oracle without a hit-index tie in the replay (ties found: {sorted(tied)[:8]})"
+        explained.extend(sorted(tied))
+        # the replay ends where the oracle stood (it is deterministic): continue the main loop from there on both sides
+        fails = common.state_diff(o.state_export(), s1, 0.0, 0.0)
+        assert not fails, f"{workload} {what}: the oracle's replay does not reproduce its own run: " + "; ".join(fails[:3])
+        assert cur == cursor
+
+    def checkpoint(what, upto):
         nonlocal forked
         sg, so = g.state_export(), o.state_export()
         bad = ((sg.view(np.uint32) != so.view(np.uint32)) & ~skip[:, None]).any(axis=0)
@@ -348,7 +417,11 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
         assert not fails, f"{workload} {what}: " + "; ".join(fails[:4])
         if bad.any():
             forked += int(bad.sum())
-            g.state_import(so)
+            explain_forks(np.nonzero(bad)[0], upto, what)
+            g.state_import(o.state_export())
+        common_state[0], common_state[1], common_state[2] = o.state_export(), cursor, upto
+
+    checkpoint("start", 0)
 
     for it in range(iters):
         cnt = []
@@ -360,19 +433,21 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
         cg, co = cnt
         for c in (g, o):
             c.pixel_index_update(npix, int(co[Q.RAYGEN]))
+        cursor = (cursor + int(co[Q.RAYGEN])) % npix
         rays += int(co[Q.EXTENSION]) + int(co[Q.SHADOW]); ext_rays += int(co[Q.EXTENSION])
         if not (cg == co).all():
             # a forked path entered another material queue or ended at another bounce: at most a handful of paths, and the states must say so
             assert int(np.abs(cg.astype(np.int64) - co.astype(np.int64)).sum()) <= 8, f"{workload} it{it}: counters {cg} vs {co}"
-            checkpoint(f"it{it} (counters {cg} vs {co})")
-            assert forked, f"{workload} it{it}: counters differ but the states do not"
+            before = forked
+            checkpoint(f"it{it} (counters {cg} vs {co})", it + 1)
+            assert forked > before, f"{workload} it{it}: counters differ but the states do not"
         elif it % 5 == 4 or it == iters - 1:
-            checkpoint(f"after {it + 1} iterations")
+            checkpoint(f"after {it + 1} iterations", it + 1)
     assert forked <= max(1, int(FLIP_BUDGET * ext_rays)), (workload, forked, ext_rays)
     if not forked:
         assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
     _report(f"bench_chain_vs_oracle_{workload}", {"paths": n, "iterations": iters, "rays": rays, "extension_rays": ext_rays,
-                                                  "paths_forked_by_a_tie": forked})
+                                                  "paths_forked_by_a_tie": forked, "forks_shown_to_be_ties_by_replay": len(explained)})
     g.close()
 
 
