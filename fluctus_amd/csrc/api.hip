@@ -2,6 +2,7 @@
 // CDNA4 re-layout of the BVH, asynchronous kernel sequencing on one HIP stream, measurement hooks.
 #include "flx_device.h"
 #include "flx_wide.h"
+#include "flx_wide_opt.h"
 #include "flx_trace.h"
 #include "flx_trace4.h"
 #include "../../include/fluctus_hip.h"
@@ -12,6 +13,7 @@
 #include <cstdio>
 #include <utility>
 #include <dlfcn.h>
+#include <chrono>
 #include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 is bound with dlopen at the first group call
 
 namespace flxd {
@@ -32,6 +34,7 @@ void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, co
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
 void launch_state_export(hipStream_t, const State &, float *, float);
 void launch_state_import(hipStream_t, const State &, const float *);
+void launch_math_probe(hipStream_t, int, const float *, const float *, uint32_t, uint32_t *);
 void launch_mk_reset(hipStream_t, const State &, const Frame &, const flx_render_params &);
 void launch_mk_raygen(hipStream_t, const State &, const flx_render_params &);
 void launch_mk_next_vertex(hipStream_t, const State &, const Scene &, const Frame &, const flx_render_params &, uint32_t *, uint32_t *);
@@ -109,6 +112,8 @@ struct flx_ctx {
     int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
     std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
+    int wideOpt = 0;            // passes of subtree reinsertion over the inner topology before the 4-wide collapse (flx_wide_opt.h); takes effect at the next upload
+    double wideOptStats[4] = {0, 0, 0, 0};      // SAH cost before / after, nodes moved, seconds
     int numCUs = 256;
     // multi-GPU group (flx_group_*): RCCL communicator of this rank, root-side staging
     ncclComm_t comm = nullptr;
@@ -464,7 +469,21 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     }
     // 4. the 4-wide quantised tree over the same leaves (flx_wide.h) + the depth of the binary tree (stack-spill sizing)
     flxw::WideTree wide;
-    { const char *werr = nullptr; if (!flxw::build_wide(nodes, nnodes, tris, ntris, indices, nidx, wide, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; } }
+    {
+        // the inner levels of the WIDE tree are free (flx_wide_opt.h): re-optimised over the reference's leaves before the collapse; the binary
+        // records above (extend_tree / shadow_tree 2, the microkernels) keep the reference's topology
+        const char *werr = nullptr;
+        std::vector<flx_node> optNodes; const flx_node *wsrc = nodes;
+        if (c->wideOpt > 0) {
+            flxw::OptStats os;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!flxw::optimise_topology(nodes, nnodes, c->wideOpt, optNodes, &os, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; }
+            wsrc = optNodes.data();
+            c->wideOptStats[0] = os.costBefore; c->wideOptStats[1] = os.costAfter; c->wideOptStats[2] = (double)os.moved;
+            c->wideOptStats[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        if (!flxw::build_wide(wsrc, nnodes, tris, ntris, indices, nidx, wide, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; }
+    }
     uint32_t binDepth = 1;
     {   // nodes are in DFS order with parent < child (checked above for the right child; the left child is i + 1)
         std::vector<uint16_t> depth(nnodes, 0);
@@ -1197,6 +1216,22 @@ int flx_state_import(flx_ctx *c, const float *in)
     HIPCHK(c, e);
     return 0;
 }
+int flx_math_probe(flx_ctx *c, int fn, const float *a, const float *b, uint32_t n, uint32_t *out_bits)
+{
+    MUTATES(c);
+    NEED(c, a && b && out_bits && n && fn >= 0 && fn <= 15, "flx_math_probe: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, (size_t)n * 12));
+    hipError_t e = hipMemcpyAsync(d, a, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + n, b, (size_t)n * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launch_math_probe(c->stream, fn, d, d + n, n, reinterpret_cast<uint32_t *>(d + 2 * (size_t)n)); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_bits, d + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return 0;
+}
 int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
 {
     NEED(c, q >= 0 && q < FLX_NUM_QUEUES, "bad queue id");
@@ -1245,6 +1280,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && (strcmp(name, "refill_extend") == 0 || strcmp(name, "refill_shadow") == 0)) { c->err = "flx_set_option: refill value must be 0 or refillMin (1..64) | waitMax (0..64) << 8"; return 1; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
+    if (name && strcmp(name, "wide_opt") == 0 && value >= 0 && value <= 16) { c->wideOpt = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;
 }
@@ -1253,7 +1289,8 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}, {"wide_opt", c->wideOpt},
+        {"wide_opt_ms", (int)(c->wideOptStats[3] * 1e3)}, {"wide_opt_sah_before_x100", (int)(c->wideOptStats[0] * 100.0)}, {"wide_opt_sah_after_x100", (int)(c->wideOptStats[1] * 100.0)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;
     return 1;

@@ -246,6 +246,26 @@ void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params 
 {
     hipLaunchKernelGGL(k_postprocess, dim3((fr.localPixels + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, fr, p);
 }
+// test hook: the arithmetic contract (include/flx_math.h) evaluated on the device, results as bit patterns -- the oracle's orc_math_array
+// is the other half (tests/test_gpu_parity.py::test_arithmetic_contract_device_vs_oracle)
+__global__ __launch_bounds__(MISC_BLOCK) void k_math_probe(int fn, const float *a, const float *b, uint32_t n, uint32_t *out)
+{
+    const uint32_t i = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    float r = 0.0f;
+    switch (fn) {
+    case 0: r = sinf_(x); break; case 1: r = cosf_(x); break; case 2: r = tanf_(x); break; case 3: r = atan2f_(x, y); break;
+    case 4: r = acosf_(x); break; case 5: r = powf_(x, y); break; case 6: r = logf_(x); break; case 7: r = expf_(x); break;
+    case 8: r = asinf_(x); break; case 9: r = atanf_(x); break; case 10: r = fminf_(x, y); break; case 11: r = fmaxf_(x, y); break;
+    case 12: r = x / y; break; case 13: r = sqrtf(x); break; case 14: r = x * y; break; case 15: r = x + y; break;
+    }
+    out[i] = __float_as_uint(r);
+}
+void launch_math_probe(hipStream_t s, int fn, const float *a, const float *b, uint32_t n, uint32_t *out)
+{
+    hipLaunchKernelGGL(k_math_probe, dim3((n + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, fn, a, b, n, out);
+}
 void launch_state_export(hipStream_t s, const State &st, float *out, float shadowLenReset)
 {
     hipLaunchKernelGGL(k_state_export, dim3((st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, out, shadowLenReset);

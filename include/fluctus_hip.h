@@ -180,6 +180,10 @@ int flx_scene_info(flx_ctx *ctx, uint32_t *out8);
 /* ---- test hooks: path state in the reference's GPUTaskState SoA layout (64 columns x num_tasks
  * words, src/geom.h:199-236), queues and counters.  Blocking. */
 int flx_state_export(flx_ctx *ctx, float *out_64xN);
+/* the arithmetic contract (include/flx_math.h) evaluated on the device over n operand pairs, results as bit patterns.  fn: 0 sin, 1 cos,
+ * 2 tan, 3 atan2(a, b), 4 acos, 5 pow(a, b), 6 log, 7 exp, 8 asin, 9 atan, 10 fmin, 11 fmax, 12 a / b, 13 sqrt, 14 a * b, 15 a + b.
+ * The oracle's orc_math_array is the CPU half: both sides must agree bit for bit, signed zeros included. */
+int flx_math_probe(flx_ctx *ctx, int fn, const float *a, const float *b, uint32_t n, uint32_t *out_bits);
 int flx_state_import(flx_ctx *ctx, const float *in_64xN);
 int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
 int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);

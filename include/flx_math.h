@@ -47,14 +47,16 @@ FLX_HD float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 /* ---------------------------------------------------------------- scalars */
 
 /* IEEE-754 minNum/maxNum (a NaN operand yields the other one) = OpenCL fmin/fmax = one
- * v_min_f32 / v_max_f32 on the device.  The two spellings agree except for the sign of a zero
- * result of min(-0,+0), which no comparison in the path can observe. */
+ * v_min_f32 / v_max_f32 on the device.  gfx9 orders the zeros: max(+0, -0) = +0 and min(+0, -0) = -0 whichever operand comes first;
+ * the host spelling does the same (AND / OR of the bit patterns of two EQUAL operands), so that a stored zero carries the same sign
+ * on both sides -- no comparison in the path observes it, but the parity tests compare stored values bit for bit
+ * (round 4: lastPdfImplicit = max(0, -0) differed in the sign bit for ~1 path in 10^6). */
 #if defined(__HIP_DEVICE_COMPILE__)
 FLX_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }
 FLX_HD float fmaxf_(float a, float b) { return __builtin_fmaxf(a, b); }
 #else
-FLX_HD float fminf_(float a, float b) { return a < b ? a : (b != b ? a : b); }
-FLX_HD float fmaxf_(float a, float b) { return a > b ? a : (b != b ? a : b); }
+FLX_HD float fminf_(float a, float b) { return a < b ? a : (b < a ? b : (a != a ? b : (b != b ? a : u2f(f2u(a) | f2u(b))))); }
+FLX_HD float fmaxf_(float a, float b) { return a > b ? a : (b > a ? b : (a != a ? b : (b != b ? a : u2f(f2u(a) & f2u(b))))); }
 #endif
 FLX_HD float clampf(float v, float lo, float hi) { return fminf_(fmaxf_(v, lo), hi); }
 FLX_HD float absf(float a) { return __builtin_fabsf(a); }

@@ -29,6 +29,15 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
 
 
+def math_array(fn, a, b):
+    """include/flx_math.h function `fn` (see orc_math) over operand arrays on the host; bit patterns."""
+    import numpy as np
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    out = np.zeros(a.size, np.uint32)
+    lib().orc_math_array(int(fn), _p(a), _p(b), C.c_uint32(a.size), _p(out))
+    return out
+
+
 class _Prefixed:
     """Attribute access L.orc_xyz -> getattr(lib, prefix + 'xyz') so one class serves both libraries."""
 

@@ -1636,8 +1636,16 @@ float orc_math(int fn, float a, float b)
     case 0: return sinf_(a); case 1: return cosf_(a); case 2: return tanf_(a);
     case 3: return atan2f_(a, b); case 4: return acosf_(a); case 5: return powf_(a, b);
     case 6: return logf_(a); case 7: return expf_(a); case 8: return asinf_(a); case 9: return atanf_(a);
+    case 10: return fminf_(a, b); case 11: return fmaxf_(a, b); case 12: return a / b; case 13: return sqrtf(a);
+    case 14: return a * b; case 15: return a + b;
     }
     return 0.0f;
+}
+/* the same over arrays, results as bit patterns (signed zeros and NaN payloads included): the oracle's half of
+ * tests/test_gpu_parity.py::test_arithmetic_contract_device_vs_oracle */
+void orc_math_array(int fn, const float *a, const float *b, uint32_t n, uint32_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = f2u(orc_math(fn, a[i], b[i]));
 }
 uint32_t orc_hash(uint32_t s) { return hash_u32(s); }
 

@@ -537,3 +537,33 @@ def test_device_vs_reference_kernel_outputs(tag):
         col_rtol = {COL.LAST_PDF_W: np.where(common.sharp_lobe_paths(d, sb), 2e-2, 1e-3)} if names[k] == "materials" else None      # (ill-conditioned in the reference itself: common.sharp_lobe_paths)
         fails = common.state_diff(sa, sb, 1e-3 if names[k] == "materials" else 1e-4, 1e-5, mask=mask, col_rtol=col_rtol)
         assert not fails, f"step {k} {names[k]}: " + "; ".join(fails[:4])
+
+
+def test_arithmetic_contract_device_vs_oracle():
+    """include/flx_math.h is the arithmetic contract both sides compile: every function of it (own sin / cos / tan / atan2 / acos / asin /
+    atan / pow / log / exp, IEEE division and sqrt, fmin / fmax with their ordering of signed zeros) evaluated on the device
+    (flx_math_probe) and on the host (orc_math_array) over random operands, the special values and every pairing of +-0, +-inf, NaN:
+    identical bit patterns.  (Round 4: the host spelling of fmax returned -0 for max(0, -0), v_max_f32 returns +0 -- invisible to every
+    comparison in the path, visible as a sign bit in a stored lastPdfImplicit for ~1 path in 10^6.)"""
+    from fluctus_amd.device import HipContext
+    from oracle import binding as ob
+    g = HipContext(1024)
+    rng = np.random.RandomState(7)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, -3.4028235e38, 0.5, -0.5, 2.0, 1e-20, 1e20],
+                       np.float32)
+    sa, sb = [x.reshape(-1) for x in np.meshgrid(special, special)]
+    names = {0: "sin", 1: "cos", 2: "tan", 3: "atan2", 4: "acos", 5: "pow", 6: "log", 7: "exp", 8: "asin", 9: "atan", 10: "fmin", 11: "fmax",
+             12: "div", 13: "sqrt", 14: "mul", 15: "add"}
+    dom = {0: (-8000, 8000), 1: (-8000, 8000), 2: (-1.5, 1.5), 3: (-4, 4), 4: (-1, 1), 5: (1e-3, 4), 6: (1e-6, 1e6), 7: (-80, 80), 8: (-1, 1), 9: (-50, 50),
+           10: (-3, 3), 11: (-3, 3), 12: (-100, 100), 13: (0, 1e6), 14: (-1e3, 1e3), 15: (-1e3, 1e3)}
+    for fn, name in names.items():
+        lo, hi = dom[fn]
+        a = np.concatenate([rng.uniform(lo, hi, 200000).astype(np.float32), sa]) if fn in (10, 11, 12, 14, 15) else rng.uniform(lo, hi, 200000).astype(np.float32)
+        b = np.concatenate([rng.uniform(lo, hi, 200000).astype(np.float32), sb]) if fn in (10, 11, 12, 14, 15) else (rng.uniform(-4, 4, a.size) if fn == 3 else rng.uniform(0.2, 3.0, a.size)).astype(np.float32)
+        if fn in (10, 11):                           # plenty of equal operands and zeros of either sign
+            b[:50000] = a[:50000]; a[50000:60000] = 0.0; b[50000:55000] = -0.0; b[55000:60000] = 0.0; a[55000:57000] = -0.0
+        dv, hv = g.math_probe(fn, a, b), ob.math_array(fn, a, b)
+        nan = np.isnan(dv.view(np.float32)) & np.isnan(hv.view(np.float32))      # (NaN payloads / signs are not part of the contract)
+        bad = (dv != hv) & ~nan
+        assert not bad.any(), f"{name}: {int(bad.sum())} of {a.size} results differ, first: {name}({a[bad][0]!r}, {b[bad][0]!r}) = {dv[bad][0]:#010x} (device) vs {hv[bad][0]:#010x} (host)"
+    g.close()

@@ -366,7 +366,7 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
     common_state = [None, 0, 0]                           # oracle state, cursor, iteration count at the last point both sides were identical
     explained = []
 
-    def explain_forks(bad_paths, upto, what):
+    def explain_forks(bad_paths, upto, what, sg_main, so_main):
         """A path whose state differs at a checkpoint must have been forked by a TIE: replay the stretch since the last common state on
         both sides, this time looking after every extension launch (the pattern of _free_run_default_vs_oracle), and demand that every
         differing path shows, at the launch where it first differs, hit records that differ in `i` but agree in `t` to 1e-5 -- anything
@@ -402,6 +402,13 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
                 c.clear_queues(); c.finish(); c.pixel_index_update(npix, int(coj[Q.RAYGEN]))
             cur = (cur + int(coj[Q.RAYGEN])) % npix
         unexplained = sorted(set(int(x) for x in bad_paths) - tied)
+        if unexplained:                                   # diagnostics: which columns of the main run's states differ, and the replay's view of the same paths
+            sgr, sor = g.state_export(), o.state_export()
+            for x in unexplained[:4]:
+                cols = [c for c in range(64) if not skip[c] and sg_main.view(np.uint32)[c][x] != so_main.view(np.uint32)[c][x]]
+                print(f"[fork] path {x}: main run differs in " + ", ".join(f"{common.colname(c)}: {sg_main[c][x]!r}/{sg_main.view(np.uint32)[c][x]:#x} vs {so_main[c][x]!r}/{so_main.view(np.uint32)[c][x]:#x}" for c in cols))
+                colsr = [c for c in range(64) if not skip[c] and sgr.view(np.uint32)[c][x] != sor.view(np.uint32)[c][x]]
+                print(f"[fork] path {x}: after the replay device vs oracle differ in {[common.colname(c) for c in colsr]}")
         assert not unexplained, f"{workload} {what}: paths {unexplained[:8]} differ from the oracle without a hit-index tie in the replay (ties found: {sorted(tied)[:8]})"
         explained.extend(sorted(tied))
         # the replay ends where the oracle stood (it is deterministic): continue the main loop from there on both sides
@@ -417,7 +424,7 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
         assert not fails, f"{workload} {what}: " + "; ".join(fails[:4])
         if bad.any():
             forked += int(bad.sum())
-            explain_forks(np.nonzero(bad)[0], upto, what)
+            explain_forks(np.nonzero(bad)[0], upto, what, sg, so)
             g.state_import(o.state_export())
         common_state[0], common_state[1], common_state[2] = o.state_export(), cursor, upto
 
