@@ -119,7 +119,7 @@ def capture_key(args, ctx, p, C=1):
     return {"workload": args.workload, "width": int(p["width"]), "height": int(p["height"]), "max_bounces": int(p["maxBounces"]),
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
-            "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"), "wide_opt": ctx.get_option("wide_opt"),
+            "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"),
             "source_hash": build.source_hash()}
 
 
@@ -191,7 +191,6 @@ def main():
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
-    ap.add_argument("--wide-opt", type=int, default=-1, help="passes of subtree reinsertion over the 4-wide tree's inner topology at upload (-1 = library default)")
     ap.add_argument("--eager-bump", type=int, default=0)
     ap.add_argument("--kernel-timing", type=int, default=3, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel (roofline) only")
     args = ap.parse_args()
@@ -230,8 +229,6 @@ def main():
         c_.set_option("shadow_tree", args.shadow_tree)
         c_.set_option("overlap", args.overlap)
         c_.set_option("node_layout", args.node_layout)
-        if args.wide_opt >= 0:
-            c_.set_option("wide_opt", args.wide_opt)
         c_.set_option("eager_bump", args.eager_bump)
         c_.set_option("fuse", args.fuse)
         if args.refill_extend >= 0:
@@ -550,7 +547,6 @@ def main():
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
                        "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
                        "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
-                       "wide_opt_passes": ctx.get_option("wide_opt"), "wide_opt_upload_ms": ctx.get_option("wide_opt_ms"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},

@@ -2,7 +2,6 @@
 // CDNA4 re-layout of the BVH, asynchronous kernel sequencing on one HIP stream, measurement hooks.
 #include "flx_device.h"
 #include "flx_wide.h"
-#include "flx_wide_opt.h"
 #include "flx_trace.h"
 #include "flx_trace4.h"
 #include "../../include/fluctus_hip.h"
@@ -13,7 +12,6 @@
 #include <cstdio>
 #include <utility>
 #include <dlfcn.h>
-#include <chrono>
 #include <rccl/rccl.h>      // types and prototypes only: librccl.so.1 is bound with dlopen at the first group call
 
 namespace flxd {
@@ -46,6 +44,9 @@ void launch_deinterleave(hipStream_t, const float *, float *, uint32_t, uint32_t
 }
 
 using namespace flxd;
+#ifdef FLX_LAB_RSTATS
+namespace flxd { extern unsigned long long *g_lab_rstats; }
+#endif
 
 static thread_local std::string g_create_error;
 
@@ -57,20 +58,18 @@ struct flx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;              // the shadow kernel runs here, concurrently with the extension kernel
     hipEvent_t evPreExt = nullptr, evShadow = nullptr, evPostLogic = nullptr;
-    bool overlapOK = false;                     // true between flx_wf_extend and the next enqueue
-    bool logicChain = false, logicChainPrev = false;   // only raygen / materials / extend enqueued since flx_wf_logic
+    int phase = 0;                              // the call-sequence state machine (enum Phase below): ONE explicit state instead of deferral / chain booleans
     int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
     int overlapOpt = -1;                        // option "overlap": -1 = the default (pickSchedule), else as set
     uint32_t *spill2 = nullptr;
     // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
     // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
-    // settles the deferred calls first, so no call ever observes a state the separate kernels would not have produced.
+    // takes one step of the state machine first (enter()), so no call ever observes a state the separate kernels would not have produced.
     int fuse = 1;
     int extOrder = 0;                           // fused pass: extension queue lists the continuing paths 1 by path id | 0 one segment per material queue; chosen at flx_upload_scene
     int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 31 all six; chosen at flx_upload_scene
-    int pend = 0;                               // 0 nothing deferred | 1 flx_wf_logic | 2 flx_wf_logic, flx_wf_raygen
-    int pendFirst = 0;                          // the deferred flx_wf_logic's `first`
+    int pendFirst = 0;                          // the deferred flx_wf_logic's `first` (phases PH_DEFER_*)
     bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
     uint32_t numTasks = 0;
     std::string err;
@@ -101,8 +100,8 @@ struct flx_ctx {
     int refillShadowOpt = -1;                   // option "refill_shadow": -1 = the default (off), else as set
     // The persistent-wave extension kernel leaves RAW hit records (flx_trace.h): true from flx_wf_extend until they are committed -- by the
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
-    // or by k_materialise as soon as any other entry point runs (settle; the calls of the steady-state loop set keepRaw first).
-    bool rawHits = false, keepRaw = false;
+    // or by k_materialise as soon as an entry point that could observe a hit record runs (transition(): commitRaw).
+    bool rawHits = false;
     bool cursorDirty[2] = {false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
@@ -112,8 +111,6 @@ struct flx_ctx {
     int denoiser = 0;           // USE_OPTIX_DENOISER of the reference: accumulate the denoiser feature buffers
     std::vector<void *> aovAllocs;
     int nodeLayout = 1;         // 1 = sibling-pair record numbering (see flx_upload_scene), 0 = DFS
-    int wideOpt = 0;            // passes of subtree reinsertion over the inner topology before the 4-wide collapse (flx_wide_opt.h); takes effect at the next upload
-    double wideOptStats[4] = {0, 0, 0, 0};      // SAH cost before / after, nodes moved, seconds
     int numCUs = 256;
     // multi-GPU group (flx_group_*): RCCL communicator of this rank, root-side staging
     ncclComm_t comm = nullptr;
@@ -204,12 +201,48 @@ static int allocFrame(flx_ctx *c)
 
 extern "C" {
 
-// Every entry point that enqueues work or changes device state breaks the two "what came before" chains that let
-// flx_wf_shadow run ahead on the second stream; the few calls that are safe to run ahead of restore them (KEEP_CHAIN).
-static int settle(flx_ctx *c);
-#define MUTATES_DEFERRING(c) do { (c)->overlapOK = false; (c)->logicChainPrev = (c)->logicChain; (c)->logicChain = false; } while (0)
-#define MUTATES(c) do { if (settle(c)) return 1; MUTATES_DEFERRING(c); } while (0)
-#define KEEP_CHAIN(c) do { (c)->logicChain = (c)->logicChainPrev; } while (0)
+// ---- The call-sequence state machine.  The library defers and fuses behind the reference's entry points; what may be deferred, fused,
+// left raw or started early depends on WHAT WAS CALLED SINCE -- one explicit phase, one transition function, every entry point declares
+// its class of call.  (Rounds 2-3 kept this in ten booleans and five macros; tests/test_gpu_fuzz.py covers the (phase, call) pairs.)
+//   PH_IDLE                nothing deferred, nothing known about the calls since the last `logic`
+//   PH_DEFER_LOGIC         flx_wf_logic was called and is DEFERRED: the next call decides whether it runs fused with the material kernels
+//   PH_DEFER_LOGIC_RAYGEN  ... and flx_wf_raygen behind it, deferred along (its queue does not exist yet)
+//   PH_CHAIN               `logic` has been launched and only genRays / material kernels were enqueued since: the shadow kernel's inputs are
+//                          complete and nothing enqueued since touches them (flx_wf_shadow below)
+//   PH_CHAIN_EXT           ... and the extension kernel is the last thing enqueued: flx_wf_shadow may start right behind `logic` (overlap 2)
+//   PH_EXT                 the extension kernel is the last thing enqueued, the chain since `logic` is broken: flx_wf_shadow runs beside it (overlap 1, 2)
+// Orthogonal DATA flags stay what they are: rawHits (hit records of the last extension launch are RAW, flx_trace.h), matQueuesEmpty,
+// qs.extPend (lazy extension counter), cursorDirty.
+enum Phase { PH_IDLE = 0, PH_DEFER_LOGIC = 1, PH_DEFER_LOGIC_RAYGEN = 2, PH_CHAIN = 3, PH_CHAIN_EXT = 4, PH_EXT = 5 };
+enum Call {
+    CALL_LOGIC, CALL_RAYGEN, CALL_MATERIALS, CALL_EXTEND, CALL_SHADOW,
+    CALL_QUIET,        // enqueues at most a read-back of counters / nothing: flx_get_counters_async, flx_finish, flx_counter_totals, flx_profile_enable
+    CALL_NEUTRAL,      // touches counters, cursor or framebuffer, never a hit record: flx_clear_queues, flx_pixel_index_*, flx_end_iteration_async, flx_read_pixels
+    CALL_PEEK,         // may observe hit records or queues, or changes how later kernels run, without enqueueing work of its own: flx_stream, flx_queue_read, trace-stat getters, plain options
+    CALL_OBSERVE       // everything else: exports, imports, uploads, parameters, resets, options that re-plan the schedule, the microkernels, the gather
+};
+struct Step { bool launchDeferred, commitRaw; int next; };
+static Step transition(int ph, Call call)
+{
+    const bool deferred = ph == PH_DEFER_LOGIC || ph == PH_DEFER_LOGIC_RAYGEN;
+    const bool chain = deferred || ph == PH_CHAIN || ph == PH_CHAIN_EXT;       // only genRays / materials / extension since `logic`
+    switch (call) {
+    case CALL_LOGIC:     return {deferred, false, PH_IDLE};                     // (flx_wf_logic then enters PH_DEFER_LOGIC or PH_CHAIN; it hands RAW records to the fused pass or commits them itself)
+    case CALL_RAYGEN:    if (ph == PH_DEFER_LOGIC) return {false, false, PH_DEFER_LOGIC_RAYGEN};
+                         return {deferred, false, chain ? PH_CHAIN : PH_IDLE};  // genRays reads no hit record (and its paths' records are dead: flx_device.h)
+    case CALL_MATERIALS: if (deferred) return {false, false, PH_CHAIN};         // the fused pass runs now (flx_wf_materials)
+                         return {false, true, chain ? PH_CHAIN : PH_IDLE};      // the separate material kernels read the hit records
+    case CALL_EXTEND:    return {deferred, true, chain ? PH_CHAIN_EXT : PH_EXT};   // (a second extension launch needs the first one's records committed: pathLen)
+    case CALL_SHADOW:    return {deferred, false, PH_IDLE};                     // {shadowOrig, shadowDir} -> shadowRayBlocked: no hit record
+    case CALL_QUIET:     return {deferred, false, deferred ? PH_CHAIN : ph};
+    case CALL_NEUTRAL:   return {deferred, false, PH_IDLE};
+    case CALL_PEEK:      return {deferred, true, deferred ? PH_CHAIN : ph};
+    case CALL_OBSERVE:   return {deferred, true, PH_IDLE};
+    }
+    return {deferred, true, PH_IDLE};
+}
+static int enter(flx_ctx *c, Call call);
+#define ENTER(c, call) do { if (enter(c, call)) return 1; } while (0)
 // lazy extension counter (flx_device.h): make counters[EXTENSION] in memory current before anything outside the
 // raygen / material / extension / end-of-iteration kernels looks at it or overwrites the source counters
 static void flushExt(flx_ctx *c) { if (c->qs.extPend) { launch_bump_extension(c->stream, c->qs.counters, c->qs.extPend); c->qs.extPend = 0; } }
@@ -273,6 +306,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
     if (dalloc(c, c->fixedAllocs, &c->stats, FLX_NUM_TRACE_STATS)) return fail("hipMalloc(stats)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream);
+#ifdef FLX_LAB_RSTATS
+    flxd::g_lab_rstats = c->stats;
+#endif
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
@@ -299,7 +335,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
 int flx_destroy(flx_ctx *c)
 {
     if (!c) return 0;
-    c->pend = 0;                                        // deferred kernels of a context that is going away: dropped
+    c->phase = PH_IDLE;                                 // deferred kernels of a context that is going away: dropped
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { flx_group_destroy(c); }
@@ -321,7 +357,7 @@ int flx_destroy(flx_ctx *c)
 
 uint32_t flx_num_tasks(flx_ctx *c) { return c->numTasks; }
 // (an interop caller enqueues its own work behind ours on this stream: a deferred flx_wf_logic / flx_wf_raygen must be in it by then)
-void *flx_stream(flx_ctx *c) { (void)settle(c); return (void *)c->stream; }
+void *flx_stream(flx_ctx *c) { (void)enter(c, CALL_PEEK); return (void *)c->stream; }
 
 // How the two traversals share the machine.  Two persistent kernels cannot run side by side (each fills every wave slot), so the second stream
 // serves the THREAD-PER-RAY any-hit kernel: started right after `logic` (schedule 2) it runs beside genRays / the material kernels and then
@@ -341,7 +377,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
                      const void *nodesv, size_t nnodes, const void *materials, size_t nmat,
                      const void *texdesc, size_t ntex, const uint8_t *texdata, size_t texbytes)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, trisv && ntris && indices && nidx && nodesv && nnodes, "flx_upload_scene: empty scene");
     NEED(c, materials && nmat, "flx_upload_scene: at least the default material is required");
     HIPCHK(c, hipSetDevice(c->device));
@@ -468,22 +504,11 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         shade[i].d = make_float4(t.v1.t.y, t.v2.t.x, t.v2.t.y, fm);
     }
     // 4. the 4-wide quantised tree over the same leaves (flx_wide.h) + the depth of the binary tree (stack-spill sizing)
+    // (Round 4 re-optimised the inner topology over the reference's leaves before this collapse -- subtree reinsertion, archived in
+    //  scripts/experiments/flx_wide_opt.h: node visits -0.8 % kitchen / -5 % conference / -1.3 % courtyard on the device, both traversal
+    //  kernels within 0-3 %, 25 s more upload time on the courtyard; below the bar, not shipped.  profiles/r04_wide_opt_ab.txt)
     flxw::WideTree wide;
-    {
-        // the inner levels of the WIDE tree are free (flx_wide_opt.h): re-optimised over the reference's leaves before the collapse; the binary
-        // records above (extend_tree / shadow_tree 2, the microkernels) keep the reference's topology
-        const char *werr = nullptr;
-        std::vector<flx_node> optNodes; const flx_node *wsrc = nodes;
-        if (c->wideOpt > 0) {
-            flxw::OptStats os;
-            const auto t0 = std::chrono::steady_clock::now();
-            if (!flxw::optimise_topology(nodes, nnodes, c->wideOpt, optNodes, &os, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; }
-            wsrc = optNodes.data();
-            c->wideOptStats[0] = os.costBefore; c->wideOptStats[1] = os.costAfter; c->wideOptStats[2] = (double)os.moved;
-            c->wideOptStats[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        }
-        if (!flxw::build_wide(wsrc, nnodes, tris, ntris, indices, nidx, wide, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; }
-    }
+    { const char *werr = nullptr; if (!flxw::build_wide(nodes, nnodes, tris, ntris, indices, nidx, wide, &werr)) { c->err = std::string("flx_upload_scene: ") + werr; return 1; } }
     uint32_t binDepth = 1;
     {   // nodes are in DFS order with parent < child (checked above for the right child; the left child is i + 1)
         std::vector<uint16_t> depth(nnodes, 0);
@@ -551,7 +576,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
 
 int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *prob, const int *alias, const float *pdf)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, rgb && prob && alias && pdf && w > 0 && h > 0, "flx_upload_envmap: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
@@ -571,7 +596,7 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
 
 int flx_set_params(flx_ctx *c, const void *p240)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, p240, "flx_set_params: null");
     HIPCHK(c, hipSetDevice(c->device));
     memcpy(&c->params, p240, sizeof(flx_render_params));   // kernels receive the struct by value at launch = in-order semantics
@@ -582,17 +607,17 @@ int flx_set_params(flx_ctx *c, const void *p240)
 
 int flx_set_partition(flx_ctx *c, uint32_t rank, uint32_t nranks)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, nranks >= 1 && rank < nranks, "flx_set_partition: bad rank");
     c->fr.rank = rank; c->fr.nranks = nranks;
     return c->haveParams ? allocFrame(c) : 0;
 }
 uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 
-#define READY(c) do { MUTATES(c); NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
+#define READY(c, call) do { ENTER(c, call); NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
-int flx_wf_reset(flx_ctx *c) { READY(c); flushExt(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
 // Appending a source queue a second time before the pending lengths were folded into the counter would compute slots from
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
@@ -620,7 +645,9 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
     // RAW hit records are committed by the fused pass itself when genRays follows in the same chain (logic.hip: k_logic<FUSE, RAW>); the plain
     // kernel and a chain without genRays get them committed first
-    const int raw = (c->rawHits && fused != 0 && raygenFirst) ? 1 : 0;
+    // ... and only when the pass covers EVERY path: with `first` set, logic stops at min(numTasks, pixels) (src/wf_logic.cl:45-48) and the paths
+    // beyond would keep their RAW records (found by tests/test_gpu_fuzz.py, round 4)
+    const int raw = (c->rawHits && fused != 0 && raygenFirst && !first) ? 1 : 0;
     if (!raw && materialise(c)) return 1;
     c->rawHits = false;
     flushExt(c);                                       // logic's scan overwrites the source-queue counters
@@ -634,40 +661,36 @@ static uint32_t materialBits(const flx_ctx *c)
 {
     return c->params.wfSeparateQueues ? ((1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA)) : (1u << FLX_Q_DIFFUSE);
 }
-// launch what flx_wf_logic / flx_wf_raygen deferred, as the separate kernels (the caller is not flx_wf_materials)
-static int settle(flx_ctx *c)
+// one step of the state machine: launch what flx_wf_logic / flx_wf_raygen deferred as the separate kernels (the caller is not the
+// flx_wf_materials that fuses them), commit RAW hit records if the call could observe one, enter the next phase
+static int enter(flx_ctx *c, Call call)
 {
-    const bool keep = c->keepRaw; c->keepRaw = false;
-    const int pd = c->pend;
-    if (!pd) return keep ? 0 : materialise(c);
-    c->pend = 0;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (runLogic(c, c->pendFirst, 0, 0)) return 1;     // (commits RAW hit records first)
-    if (pd == 2 && runRaygen(c)) return 1;
+    const Step st = transition(c->phase, call);
+    if (st.launchDeferred) {
+        const bool withRaygen = c->phase == PH_DEFER_LOGIC_RAYGEN;
+        c->phase = PH_CHAIN;
+        HIPCHK(c, hipSetDevice(c->device));
+        if (runLogic(c, c->pendFirst, 0, 0)) return 1;     // (commits RAW hit records first)
+        if (withRaygen && runRaygen(c)) return 1;
+    }
+    if (st.commitRaw && materialise(c)) return 1;
+    c->phase = st.next;
     return 0;
 }
-// entry points of the steady-state loop that neither read nor write hit records: RAW ones may stay until the next fused logic pass
-#define KEEP_RAW(c) do { (c)->keepRaw = true; } while (0)
 int flx_wf_raygen(flx_ctx *c)
 {
-    KEEP_RAW(c);                                       // genRays reads no hit record (and its paths' records are dead: flx_device.h)
-    if (c->pend == 1) {                                // deferred behind the deferred flx_wf_logic (its queue does not exist yet)
-        c->keepRaw = false;                            // (no settle on this path to consume it)
-        MUTATES_DEFERRING(c); KEEP_CHAIN(c);
-        c->pend = 2;
-        return 0;
-    }
-    READY(c); KEEP_CHAIN(c);
+    if (c->phase == PH_DEFER_LOGIC) { ENTER(c, CALL_RAYGEN); return 0; }      // deferred behind the deferred flx_wf_logic (its queue does not exist yet)
+    READY(c, CALL_RAYGEN);
     return runRaygen(c);
 }
 int flx_wf_extend(flx_ctx *c)
 {
-    READY(c);
-    KEEP_CHAIN(c);
+    READY(c, CALL_EXTEND);
+    const bool chainIntact = c->phase == PH_CHAIN_EXT;
     // "everything enqueued before the extension kernel": what a concurrent shadow kernel waits for -- unless it may start right after
     // `logic` (overlap 2 with the chain intact: it then waits for evPostLogic instead, and this marker would only put one more barrier
     // packet in front of the extension kernel)
-    if (c->overlap && !(c->overlap == 2 && c->logicChain)) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));
+    if (c->overlap && !(c->overlap == 2 && chainIntact)) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
@@ -681,7 +704,6 @@ int flx_wf_extend(flx_ctx *c)
         else launch_extend(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
-    c->overlapOK = c->overlap != 0;
     return 0;
 }
 int flx_wf_shadow(flx_ctx *c)
@@ -698,10 +720,9 @@ int flx_wf_shadow(flx_ctx *c)
     // init_path_state's writes to shadowRayBlocked / shadowRayLen touch other paths.  So if ONLY those calls came since
     // flx_wf_logic, the second stream waits for logic alone and the latency-bound shadow traversal also overlaps the
     // HBM-bound raygen and material kernels.
-    const bool overlapped = c->overlapOK;
-    const bool early = overlapped && c->overlap == 2 && c->logicChain;
-    KEEP_RAW(c);                                       // shadow rays: {shadowOrig, shadowDir} -> shadowRayBlocked
-    READY(c);
+    const bool overlapped = (c->phase == PH_CHAIN_EXT || c->phase == PH_EXT) && c->overlap != 0;
+    const bool early = c->phase == PH_CHAIN_EXT && c->overlap == 2;
+    READY(c, CALL_SHADOW);
     hipStream_t s = c->stream;
     if (overlapped) { s = c->stream2; HIPCHK(c, hipStreamWaitEvent(s, early ? c->evPostLogic : c->evPreExt, 0)); }
     hipEvent_t earlyStart = nullptr;
@@ -731,32 +752,30 @@ int flx_wf_shadow(flx_ctx *c)
 }
 int flx_wf_logic(flx_ctx *c, int first)
 {
-    KEEP_RAW(c);                                       // (runLogic commits RAW hit records, or hands them to the fused pass)
-    READY(c);
+    READY(c, CALL_LOGIC);                              // (runLogic commits RAW hit records, or hands them to the fused pass)
     // fused with the material kernels if flx_wf_materials follows (see flx_ctx::fuse).  The fused scatter numbers the material
     // queues from zero, so they must be empty now (cleared since the last logic: the reference clears all queues every iteration,
     // src/tracer.cpp:257); otherwise, and with the option off, the kernel runs here and now.
     const uint32_t allMat = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
     // (with a single material queue every BSDF type sits in the diffuse list: only a pass that inlines them all can serve it)
     const bool fusable = c->params.wfSeparateQueues || fused_queue_mask(c->fuseSet) == allMat;
-    if (c->fuse && c->matQueuesEmpty && fusable) { c->pend = 1; c->pendFirst = first; }
-    else if (runLogic(c, first, 0, 0)) return 1;
-    if (c->overlap == 2) c->logicChain = true;
+    if (c->fuse && c->matQueuesEmpty && fusable) { c->phase = PH_DEFER_LOGIC; c->pendFirst = first; }
+    else { if (runLogic(c, first, 0, 0)) return 1; c->phase = PH_CHAIN; }
     return 0;
 }
 int flx_wf_materials(flx_ctx *c)
 {
-    const int pd = c->pend;
-    if (pd) {
+    const int before = c->phase;
+    if (before == PH_DEFER_LOGIC || before == PH_DEFER_LOGIC_RAYGEN) {
+        const bool withRaygen = before == PH_DEFER_LOGIC_RAYGEN;
         // [logic, materials] or [logic, raygen, materials]: one fused pass + scan + scatter, then the deferred genRays.  The
         // extension-queue slots are the ones the separate kernels compute in the caller's order: with genRays first the material
         // lists go behind the raygen queue, and genRays itself must not see them as pending yet.
-        c->pend = 0;
-        MUTATES_DEFERRING(c); KEEP_CHAIN(c);
+        ENTER(c, CALL_MATERIALS);
         NEED(c, c->haveParams && c->sc.bnodes, "set params and upload a scene first");
         HIPCHK(c, hipSetDevice(c->device));
-        if (runLogic(c, c->pendFirst, c->fuseSet, pd == 2)) return 1;
-        if (pd == 2 && runRaygen(c)) return 1;
+        if (runLogic(c, c->pendFirst, c->fuseSet, withRaygen)) return 1;
+        if (withRaygen && runRaygen(c)) return 1;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
         { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), c->extOrder); }
         LAUNCHED(c);
@@ -764,7 +783,7 @@ int flx_wf_materials(flx_ctx *c)
         if (c->eagerBump) flushExt(c);
         return 0;
     }
-    READY(c); KEEP_CHAIN(c);
+    READY(c, CALL_MATERIALS);
     const uint32_t bits = materialBits(c);
     flushExtIfPending(c, bits);
     { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials(c->stream, c->st, c->qs, c->sc, c->params.wfSeparateQueues); }
@@ -772,11 +791,11 @@ int flx_wf_materials(flx_ctx *c)
     if (c->eagerBump) flushExt(c);
     LAUNCHED(c); return 0;
 }
-int flx_postprocess(flx_ctx *c) { READY(c); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_postprocess(flx_ctx *c) { READY(c, CALL_OBSERVE); { ScopedTimer t(c, FLX_K_POSTPROCESS); launch_postprocess(c->stream, c->fr, c->params); } LAUNCHED(c); return 0; }
 
 // ---- microkernel integrator.  One path per pixel, framebuffers indexed by the path id: single-GPU only, the pixel
 // partition belongs to the wavefront path (allocFrame sizes the buffers for the rank's LOCAL pixels).
-#define MK_READY(c) do { READY(c); NEED(c, (c)->fr.nranks == 1, "the microkernel integrator is single-GPU: flx_set_partition(ctx, 0, 1) first"); } while (0)
+#define MK_READY(c) do { READY(c, CALL_OBSERVE); NEED(c, (c)->fr.nranks == 1, "the microkernel integrator is single-GPU: flx_set_partition(ctx, 0, 1) first"); } while (0)
 int flx_mk_reset(flx_ctx *c) { MK_READY(c); launch_mk_reset(c->stream, c->st, c->fr, c->params); LAUNCHED(c); return 0; }
 int flx_mk_raygen(flx_ctx *c) { MK_READY(c); launch_mk_raygen(c->stream, c->st, c->params); LAUNCHED(c); return 0; }
 int flx_mk_next_vertex(flx_ctx *c) { MK_READY(c); launch_mk_next_vertex(c->stream, c->st, c->sc, c->fr, c->params, c->spill, c->mkStats); LAUNCHED(c); return 0; }
@@ -785,7 +804,7 @@ int flx_mk_splat(flx_ctx *c) { MK_READY(c); launch_mk_splat(c->stream, c->st, c-
 int flx_mk_splat_preview(flx_ctx *c) { MK_READY(c); launch_mk_splat(c->stream, c->st, c->fr, c->params, c->mkStats, 1); LAUNCHED(c); return 0; }
 int flx_mk_stats_async(flx_ctx *c, void *out16)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, out16, "flx_mk_stats_async: null");
     HIPCHK(c, hipSetDevice(c->device));
     if ((int)c->pendingMk.size() >= c->pinnedSlots) { c->err = "too many outstanding stats reads; call flx_finish"; return 1; }
@@ -794,11 +813,11 @@ int flx_mk_stats_async(flx_ctx *c, void *out16)
     c->pendingMk.push_back({out16, slot});
     return 0;
 }
-int flx_mk_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
+int flx_mk_stats_reset(flx_ctx *c) { ENTER(c, CALL_OBSERVE); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->mkStats, 0, 16, c->stream)); return 0; }
 
 int flx_clear_queues(flx_ctx *c)
 {
-    KEEP_RAW(c); MUTATES(c);
+    ENTER(c, CALL_NEUTRAL);
     c->qs.extPend = 0; c->matQueuesEmpty = true;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
@@ -812,8 +831,7 @@ int flx_clear_queues(flx_ctx *c)
 int flx_get_counters_async(flx_ctx *c, void *out32)
 {
     NEED(c, out32, "flx_get_counters_async: null");
-    KEEP_RAW(c);
-    if (settle(c)) return 1;
+    ENTER(c, CALL_QUIET);
     HIPCHK(c, hipSetDevice(c->device));
     flushExt(c);
     if ((int)c->pending.size() >= c->pinnedSlots) { c->err = "too many outstanding counter reads; call flx_finish"; return 1; }
@@ -825,8 +843,7 @@ int flx_get_counters_async(flx_ctx *c, void *out32)
 
 int flx_finish(flx_ctx *c)
 {
-    KEEP_RAW(c);
-    if (settle(c)) return 1;
+    ENTER(c, CALL_QUIET);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
@@ -844,8 +861,7 @@ int flx_finish(flx_ctx *c)
 
 int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 {
-    KEEP_RAW(c);
-    MUTATES(c);
+    ENTER(c, CALL_NEUTRAL);
     NEED(c, npix > 0, "flx_pixel_index_update: zero pixels");
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = (uint32_t)(((uint64_t)c->hostPixelIdx + nnew) % npix);
@@ -856,8 +872,7 @@ int flx_pixel_index_update(flx_ctx *c, uint32_t npix, uint32_t nnew)
 }
 int flx_pixel_index_reset(flx_ctx *c)
 {
-    KEEP_RAW(c);
-    MUTATES(c);
+    ENTER(c, CALL_NEUTRAL);
     HIPCHK(c, hipSetDevice(c->device));
     c->hostPixelIdx = 0;
     HIPCHK(c, hipMemsetAsync(c->fr.currPixelIdx, 0, 4, c->stream));
@@ -866,8 +881,7 @@ int flx_pixel_index_reset(flx_ctx *c)
 
 int flx_end_iteration_async(flx_ctx *c)
 {
-    KEEP_RAW(c);
-    READY(c);
+    READY(c, CALL_NEUTRAL);
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend, c->qs.cursors);
     c->cursorDirty[0] = c->cursorDirty[1] = false;      // (k_end_iteration zeroes the block cursors with the counters)
     c->qs.extPend = 0;
@@ -877,8 +891,7 @@ int flx_end_iteration_async(flx_ctx *c)
 }
 int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 {
-    KEEP_RAW(c);
-    if (settle(c)) return 1;
+    ENTER(c, CALL_QUIET);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out8, c->totals, 64, hipMemcpyDeviceToHost, c->stream));
     if (reset) HIPCHK(c, hipMemsetAsync(c->totals, 0, 64, c->stream));
@@ -888,8 +901,7 @@ int flx_counter_totals(flx_ctx *c, uint64_t *out8, int reset)
 
 int flx_read_pixels(flx_ctx *c, int which, float *out)
 {
-    KEEP_RAW(c);                                       // framebuffers only
-    MUTATES(c);
+    ENTER(c, CALL_NEUTRAL);                                       // framebuffers only
     NEED(c, c->fr.pixels && out, "flx_read_pixels: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
     NEED(c, which >= 0 && which <= 5, "flx_read_pixels: which must be 0..5");
@@ -901,7 +913,7 @@ int flx_read_pixels(flx_ctx *c, int which, float *out)
 }
 int flx_copy_pixels_to_device(flx_ctx *c, void *dst)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, c->fr.pixels && dst, "flx_copy_pixels_to_device: no framebuffer");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst, c->fr.pixels, (size_t)c->fr.localPixels * 16, hipMemcpyDeviceToDevice, c->stream));
@@ -1002,7 +1014,7 @@ static void abortGroup(flx_ctx *c) { if (c->comm && g_rccl.dl) { (void)hipSetDev
 
 int flx_group_init(flx_ctx *c, uint32_t rank, uint32_t nranks, const void *id128)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, id128 && nranks >= 1 && rank < nranks, "flx_group_init: bad arguments");
     NEED(c, rccl_load(), g_rccl.err);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1037,7 +1049,7 @@ int flx_group_init_local(flx_ctx **ctxs, uint32_t n)
     flx_ctx *c0 = ctxs[0];
     bool distinct = true;
     for (uint32_t i = 0; i < n; i++) { NEED(c0, ctxs[i], "flx_group_init_local: null context"); for (uint32_t j = 0; j < i; j++) if (ctxs[i]->device == ctxs[j]->device) distinct = false; }
-    for (uint32_t i = 0; i < n; i++) { MUTATES(ctxs[i]); flx_group_destroy(ctxs[i]); }
+    for (uint32_t i = 0; i < n; i++) { ENTER(ctxs[i], CALL_OBSERVE); flx_group_destroy(ctxs[i]); }
     // (with a stand-in transport bound through FLX_RCCL_LIB the communicator path is taken whatever the devices are: tests)
     if (rccl_override()) distinct = true;
     if (distinct) {
@@ -1086,7 +1098,7 @@ static int gatherFinish(flx_ctx *root, uint32_t nranks, float *out_host)
 // (also when its own output pointer is null: the tiles are received and the error reported afterwards) or aborts the communicator.
 int flx_gather(flx_ctx *c, uint32_t root, float *out_host)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, c->comm, "flx_gather: no group (flx_group_init first)");
     NEED(c, c->fr.pixels && c->haveParams, "flx_gather: no framebuffer");
     const uint32_t R = c->fr.nranks, me = c->fr.rank, npix = c->params.width * c->params.height;
@@ -1123,7 +1135,7 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
     flx_ctx *rc = ctxs[root];
     NEED(rc, out_host, "flx_gather_local: null output");
     for (uint32_t i = 0; i < n; i++) {
-        MUTATES(ctxs[i]);
+        ENTER(ctxs[i], CALL_OBSERVE);
         NEED(rc, ctxs[i]->fr.nranks == n && ctxs[i]->fr.rank == i && ctxs[i]->fr.pixels && ctxs[i]->haveParams, "flx_gather_local: contexts are not the group of flx_group_init_local");
         NEED(rc, (ctxs[i]->comm != nullptr) != ctxs[i]->commShared, "flx_gather_local: no group (flx_group_init_local first)");
     }
@@ -1159,13 +1171,13 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
 }
 
 // ---- measurement
-int flx_profile_enable(flx_ctx *c, int on) { KEEP_RAW(c); if (settle(c)) return 1; c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
+int flx_profile_enable(flx_ctx *c, int on) { ENTER(c, CALL_QUIET); c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
 int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
 int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
-int flx_trace_stats_enable(flx_ctx *c, int on) { if (settle(c)) return 1; c->statsOn = on != 0; return 0; }
+int flx_trace_stats_enable(flx_ctx *c, int on) { ENTER(c, CALL_PEEK); c->statsOn = on != 0; return 0; }
 int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
 {
-    if (settle(c)) return 1;
+    ENTER(c, CALL_PEEK);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out7, c->stats, 56, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1173,7 +1185,7 @@ int flx_trace_stats_get(flx_ctx *c, uint64_t *out7)
 }
 int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
 {
-    if (settle(c)) return 1;
+    ENTER(c, CALL_PEEK);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out16, c->stats, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1181,19 +1193,19 @@ int flx_trace_stats_get_ex(flx_ctx *c, uint64_t *out16)
 }
 int flx_trace_stats_get_all(flx_ctx *c, uint64_t *out24)
 {
-    if (settle(c)) return 1;
+    ENTER(c, CALL_PEEK);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out24, c->stats, FLX_NUM_TRACE_STATS * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-int flx_trace_stats_reset(flx_ctx *c) { MUTATES(c); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream)); return 0; }
+int flx_trace_stats_reset(flx_ctx *c) { ENTER(c, CALL_OBSERVE); HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipMemsetAsync(c->stats, 0, FLX_NUM_TRACE_STATS * 8, c->stream)); return 0; }
 int flx_scene_info(flx_ctx *c, uint32_t *out8) { NEED(c, out8, "flx_scene_info: null"); memcpy(out8, c->wideInfo, 32); return 0; }
 
 // ---- test hooks
 int flx_state_export(flx_ctx *c, float *out)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
     HIPCHK(c, hipMalloc((void **)&d, bytes));
@@ -1206,7 +1218,7 @@ int flx_state_export(flx_ctx *c, float *out)
 }
 int flx_state_import(flx_ctx *c, const float *in)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr; size_t bytes = (size_t)FLX_NUM_COLS * c->numTasks * 4;
     HIPCHK(c, hipMalloc((void **)&d, bytes));
@@ -1218,7 +1230,7 @@ int flx_state_import(flx_ctx *c, const float *in)
 }
 int flx_math_probe(flx_ctx *c, int fn, const float *a, const float *b, uint32_t n, uint32_t *out_bits)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, a && b && out_bits && n && fn >= 0 && fn <= 15, "flx_math_probe: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     float *d = nullptr;
@@ -1235,7 +1247,7 @@ int flx_math_probe(flx_ctx *c, int fn, const float *a, const float *b, uint32_t 
 int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
 {
     NEED(c, q >= 0 && q < FLX_NUM_QUEUES, "bad queue id");
-    if (settle(c)) return 1;
+    ENTER(c, CALL_PEEK);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(out, c->qs.q[q], (size_t)c->numTasks * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1243,7 +1255,7 @@ int flx_queue_read(flx_ctx *c, int q, uint32_t *out)
 }
 int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     NEED(c, q >= 0 && q < FLX_NUM_QUEUES && n <= c->numTasks, "bad queue id / length");
     HIPCHK(c, hipSetDevice(c->device));
     if (n) HIPCHK(c, hipMemcpyAsync(c->qs.q[q], in, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
@@ -1252,7 +1264,7 @@ int flx_queue_write(flx_ctx *c, int q, const uint32_t *in, uint32_t n)
 }
 int flx_set_counters(flx_ctx *c, const void *in32)
 {
-    MUTATES(c);
+    ENTER(c, CALL_OBSERVE);
     c->qs.extPend = 0;                                  // the caller's counters are complete
     c->matQueuesEmpty = false;                          // ... and unknown here
     HIPCHK(c, hipSetDevice(c->device));
@@ -1262,36 +1274,41 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 }
 int flx_set_option(flx_ctx *c, const char *name, int value)
 {
-    if (settle(c)) return 1;
+    ENTER(c, CALL_PEEK);
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
     if (name && strcmp(name, "ext_order") == 0 && (value == 0 || value == 1)) { c->extOrder = value; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
-    if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { MUTATES(c); c->overlapOpt = value; pickSchedule(c); return 0; }
-    if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->shadowTree = value; return 0; }
-    if (name && strcmp(name, "extend_tree") == 0 && (value == 2 || value == 4)) { MUTATES(c); c->extendTree = value; return 0; }
+    if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { ENTER(c, CALL_OBSERVE); c->overlapOpt = value; pickSchedule(c); return 0; }
+    if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { ENTER(c, CALL_OBSERVE); c->shadowTree = value; return 0; }
+    if (name && strcmp(name, "extend_tree") == 0 && (value == 2 || value == 4)) { ENTER(c, CALL_OBSERVE); c->extendTree = value; return 0; }
     if (name && strcmp(name, "denoiser") == 0 && (value == 0 || value == 1)) {
-        MUTATES(c);
+        ENTER(c, CALL_OBSERVE);
         if (c->denoiser != value) { c->denoiser = value; HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream)); return allocAov(c); }
         return 0;
     }
-    if (name && strcmp(name, "refill_extend") == 0 && refill_value_ok(value)) { MUTATES(c); c->refillExt = value; return 0; }
-    if (name && strcmp(name, "refill_shadow") == 0 && (value == -1 || refill_value_ok(value))) { MUTATES(c); c->refillShadowOpt = value; pickSchedule(c); return 0; }
+    if (name && strcmp(name, "refill_extend") == 0 && refill_value_ok(value)) { ENTER(c, CALL_OBSERVE); c->refillExt = value; return 0; }
+    if (name && strcmp(name, "refill_shadow") == 0 && (value == -1 || refill_value_ok(value))) { ENTER(c, CALL_OBSERVE); c->refillShadowOpt = value; pickSchedule(c); return 0; }
     if (name && (strcmp(name, "refill_extend") == 0 || strcmp(name, "refill_shadow") == 0)) { c->err = "flx_set_option: refill value must be 0 or refillMin (1..64) | waitMax (0..64) << 8"; return 1; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
-    if (name && strcmp(name, "wide_opt") == 0 && value >= 0 && value <= 16) { c->wideOpt = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
     return 1;
+}
+// the state machine's state as one number (read-only option "phase"; tests/test_gpu_fuzz.py reports which (phase, call) pairs it exercised):
+// bits 0-2 enum Phase, bit 3 RAW hit records pending, bit 4 material queues known empty
+static int phaseCode(const flx_ctx *c)
+{
+    return c->phase | (c->rawHits ? 8 : 0) | (c->matQueuesEmpty ? 16 : 0);
 }
 int flx_get_option(flx_ctx *c, const char *name, int *value)
 {
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}, {"wide_opt", c->wideOpt},
-        {"wide_opt_ms", (int)(c->wideOptStats[3] * 1e3)}, {"wide_opt_sah_before_x100", (int)(c->wideOptStats[0] * 100.0)}, {"wide_opt_sah_after_x100", (int)(c->wideOptStats[1] * 100.0)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
+    if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;
     return 1;
 }

@@ -19,7 +19,6 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
-#include <algorithm>
 #include "../../include/fluctus_wire.h"
 
 namespace flxw {
@@ -247,47 +246,6 @@ static inline bool build_wide(const flx_node *nodes, size_t nnodes, const flx_tr
     }
     out.maxStack += 1;
     return true;
-}
-
-// Slot order inside a wide node.  The closest-hit query sorts the hit children by entry distance and the far -> near any-hit order does too,
-// so for them the slot order is irrelevant; the any-hit order "LAST hit slot first, earlier hits pushed" (flx_trace4.h: ANY_ORDER 0, rays toward
-// an area light) descends in SLOT order.  The answer is the same whatever the order (any hit), the number of nodes visited before the first
-// occluder is not: putting the child that is most likely to hold an occluder LAST makes it the one taken first.  key: 1 = surface area of the
-// child's box (ascending), 2 = number of triangles below the child (ascending), 3 = triangles per unit area (ascending), 0 = leave as built.
-// Slots are permuted in place (references and the six plane bytes of each slot); empty slots stay behind the used ones.
-static inline void reorder_slots(WideTree &w, int key)
-{
-    if (key <= 0 || (w.rootRef & FLX_WIDE_LEAF_BIT) || w.nodes.empty()) return;
-    const size_t n = w.nodes.size();
-    std::vector<double> tris(n, 0.0);
-    auto slot_ref = [](const WNode &nd, int c) { return c == 0 ? nd.c0 : c == 1 ? nd.c1 : c == 2 ? nd.c2 : nd.c3; };
-    auto byte = [](uint32_t v, int c) { return (v >> (8 * c)) & 255u; };
-    for (size_t i = n; i-- > 0;) {                                         // children are numbered after their parent
-        WNode &nd = w.nodes[i];
-        double cnt[4], area[4]; uint32_t refs[4]; int used = 0;
-        for (int c = 0; c < 4; c++) {
-            refs[c] = slot_ref(nd, c);
-            cnt[c] = 0.0; area[c] = 0.0;
-            if (refs[c] == FLX_WIDE_EMPTY) continue;
-            used = c + 1;
-            if (refs[c] & FLX_WIDE_LEAF_BIT) { int k; memcpy(&k, &w.leafdata[refs[c] & FLX_WIDE_OFF_MASK].w, 4); cnt[c] = k; }
-            else cnt[c] = tris[refs[c]];
-            const double ex = (double)(byte(nd.qhix, c) - (double)byte(nd.qlox, c)) * nd.sx, ey = (double)(byte(nd.qhiy, c) - (double)byte(nd.qloy, c)) * nd.sy,
-                         ez = (double)(byte(nd.qhiz, c) - (double)byte(nd.qloz, c)) * nd.sz;
-            area[c] = ex * ey + ey * ez + ez * ex;
-            tris[i] += cnt[c];
-        }
-        int perm[4] = {0, 1, 2, 3};
-        auto val = [&](int c) { return key == 1 ? area[c] : key == 2 ? cnt[c] : (area[c] > 0.0 ? cnt[c] / area[c] : 1e300); };
-        std::stable_sort(perm, perm + used, [&](int a, int b) { return val(a) < val(b); });
-        uint32_t q[6] = {nd.qlox, nd.qloy, nd.qloz, nd.qhix, nd.qhiy, nd.qhiz}, qn[6] = {0, 0, 0, 0, 0, 0}, rn[4];
-        for (int c = 0; c < 4; c++) {
-            rn[c] = refs[perm[c]];
-            for (int k = 0; k < 6; k++) qn[k] |= byte(q[k], perm[c]) << (8 * c);
-        }
-        nd.c0 = rn[0]; nd.c1 = rn[1]; nd.c2 = rn[2]; nd.c3 = rn[3];
-        nd.qlox = qn[0]; nd.qloy = qn[1]; nd.qloz = qn[2]; nd.qhix = qn[3]; nd.qhiy = qn[4]; nd.qhiz = qn[5];
-    }
 }
 
 } // namespace flxw

@@ -107,6 +107,12 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             lenBits += 1u;                                                  // pathLen += 1
         }
         const uint32_t len = lenBits & ~FLX_FRESH;                         // flag bits of a regenerated path: flx_device.h
+        // A regenerated path carries genRays' reset values in the members its flags cover (flx_device.h: REGENERATED PATHS) -- values the slot
+        // does not hold, because k_raygen skips those stores.  The reference's loop never runs `logic` on a path before an extension kernel has
+        // traced it, but a host may (logic -> genRays -> logic): such a path must see EMPTY_HIT (src/wf_raygen.cl:95-96) and terminate as a
+        // miss like the reference's, not shade the slot's previous hit.  Found by tests/test_gpu_fuzz.py (round 4).
+        const bool fresh = (lenBits & FLX_FRESH) != 0u;                    // no material kernel since regeneration: lastSpecular is genRays' 1
+        if (fresh && len == 0u && !isRaw) { hitI = -1; hitMat = -1; hitN = mk3(0.0f); hflags = 0u; hitUV = mk2(0.0f, 0.0f); }
         bool Tdirty = false;
 
         // russian roulette (src/wf_logic.cl:60-69)
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
 
         if (hitI < 0 && !terminate) {                                 // implicit environment sample, :84-107
             float weight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
+            const bool lastSpecular = fresh || __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
             f3 bg = mk3(0.0f);
             if (p.useEnvMap && (len == 1u || p.sampleImpl)) bg = eval_env_dir(sc, rayDir) * p.envMapStrength;
             if (p.sampleImpl && p.sampleExpl && p.useEnvMap && len > 1u && !lastSpecular) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
             terminate = true;
         } else if (p.useAreaLight && (hflags & 1u) && !terminate) {   // implicit area-light sample, :111-131
             float misWeight = 1.0f;
-            const bool lastSpecular = __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
+            const bool lastSpecular = fresh || __float_as_uint(rd4(st.at(S_LT, gid)).w) != 0u;
             const f3 hitP = (RAW && isRaw) ? rawP : ld3(rd4(st.at(S_HITP, gid)));
             if (p.sampleExpl && len > 1u && !lastSpecular) {
                 float directPdfA = 1.0f / (4.0f * p.areaLight.size.x * p.areaLight.size.y);
@@ -149,10 +155,16 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_logic(State st, Scene sc, Frame
         // (fetching these four records with the first batch of loads, unconditionally, instead of behind shadowRayBlocked: 110 VGPRs with the
         //  commit's shading record in flight, no gain -- profiles/r03_logic_nee_early_ab.txt)
         if (st.blocked[gid] == 0u) {
-            const float4 le = rd4(st.at(S_LEMIT, gid));
-            const float4 lb = rd4(st.at(S_LBSDF, gid));
+            float4 le = rd4(st.at(S_LEMIT, gid));
+            float4 lb = rd4(st.at(S_LBSDF, gid));
             const float4 lt = rd4(st.at(S_LT, gid));
-            const float directPdfW = rd4(st.at(S_SHD, gid)).w;
+            float directPdfW = rd4(st.at(S_SHD, gid)).w;
+            // members a regenerated path's flags cover hold genRays' reset values (flx_device.h), not what the slot stores: lastBsdf /
+            // lastPdfImplicit until a material kernel has run (logic -> genRays -> extension -> logic -> shadow -> logic without the material
+            // kernels consumes the light sample with lastBsdf = 0: found by tests/test_gpu_fuzz.py), lastEmission / lastCosTh / lastPdfDirect
+            // until logic has sampled a light
+            if (fresh) lb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if ((__float_as_uint(ei4.w) & FLX_FRESH) != 0u) { le = make_float4(0.0f, 0.0f, 0.0f, 0.0f); directPdfW = 0.0f; }
             const float lightPickProb = st.pickProb[gid];
             const float cosTh = le.w, bsdfPdfW = lb.w;
             float weight = 1.0f;

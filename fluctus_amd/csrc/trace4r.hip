@@ -36,10 +36,22 @@ namespace flxd {
 #endif
 #define R_NONE 0xFFFFFFFFu
 
+#ifdef FLX_LAB_RSTATS
+// lab build only (scripts/exp_lane_use.py): wave-level accounting of where the closest-hit kernel's instructions go -- stats[18] descent rounds,
+// [19] lanes visiting a node in them, [20] leaf phases, [21] lanes on a leaf in them, [22] triangle-loop iterations, [23] lanes testing a triangle
+unsigned long long *g_lab_rstats = nullptr;
+#define RSTAT(k, v) do { if (ANY_HIT == false && rstats) { acc[k] += (unsigned long long)(v); } } while (0)
+#else
+#define RSTAT(k, v) do { } while (0)
+#endif
+
 template <bool ANY_HIT, int ANY_ORDER>
 __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax, uint32_t *cursor)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
+#ifdef FLX_LAB_RSTATS
+    unsigned long long *rstats = aux.stats; unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
     const int QID = ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION;
     const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
     const uint32_t *queue = qs.q[QID];
@@ -130,13 +142,44 @@ __global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State 
             const int nDone = (int)__popcll(__ballot(cur == FLX_RAY_DONE));
             if (64 - (int)__popcll(mI) - nDone >= waitMax) break;
             if (blk < nblk && nDone >= refillMin && waitMax < 64) break;
+            RSTAT(0, 1); RSTAT(1, __popcll(mI));
             if (inner) wide_node_visit<ANY_HIT, ANY_ORDER>(wn, stk, r, tbest, sp, cur);
         }
+#ifdef FLX_LAB_RSTATS
+        { const uint64_t mL = __ballot(cur != FLX_RAY_DONE && (cur & FLX_WIDE_LEAF_BIT)); if (mL) { RSTAT(2, 1); RSTAT(3, __popcll(mL)); } }
+#endif
         if (cur != FLX_RAY_DONE && (cur & FLX_WIDE_LEAF_BIT)) {
+#ifdef FLX_LAB_RSTATS
+            {   // the leaf visit of flx_trace4.h with the triangle loop counted (closest hit only)
+                const float4 *lp = sc.wleaf + (cur & FLX_WIDE_OFF_MASK);
+                const float4 b0 = lp[0], b1 = lp[1];
+                const float bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b1.x, b1.y, b1.z};
+                float tnear;
+                bool hitAny = false;
+                if (slab(bmin, bmax, r.orig, r.dinv, tbest, &tnear)) {
+                    const int count = __float_as_int(b0.w);
+                    const float4 *tp = lp + 2;
+                    for (int k = 0; k < count; k++, tp += 3) {
+                        if (ANY_HIT == false && rstats) { const uint64_t m_ = __ballot(true); if (lane_id() == (uint32_t)__ffsll((long long)m_) - 1u) { atomicAdd(&rstats[22], 1ull); atomicAdd(&rstats[23], (unsigned long long)__popcll(m_)); } }
+                        float t, u, v;
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        if (moller_trumbore(r.orig, r.dir, ld3(a), ld3(b), ld3(c), &t, &u, &v) && t > 0.0f && t < tbest) {
+                            if (ANY_HIT) { hitAny = true; break; }
+                            tbest = t; ubest = u; vbest = v; tribest = __float_as_int(a.w);
+                        }
+                    }
+                }
+                if (hitAny) { occluded = true; cur = FLX_RAY_DONE; } else cur = stk.pop(sp);
+            }
+#else
             if (wide_leaf_visit<ANY_HIT, false>(sc.wleaf, r, cur, tbest, ubest, vbest, tribest, nT, nullptr)) { occluded = true; cur = FLX_RAY_DONE; }
             else cur = stk.pop(sp);
+#endif
         }
     }
+#ifdef FLX_LAB_RSTATS
+    if (ANY_HIT == false && rstats && threadIdx.x == 0) for (int k = 0; k < 4; k++) atomicAdd(&rstats[18 + k], acc[k]);
+#endif
 }
 
 // The commit of traceExtension for every path whose hit record is still raw (flx_trace.h: RAW HIT RECORDS): what k_logic<FUSE, RAW> does in
@@ -201,6 +244,9 @@ void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     const int refillMin = (refill & 0xFF) ? (refill & 0xFF) : 1, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;      // (refillMin 0 would spin: api.hip, refill_value_ok)
     static int occ = 0;
     TraceAux aux{spill, ((st.numTasks + 255u) / 256u) * 256u, nullptr};
+#ifdef FLX_LAB_RSTATS
+    aux.stats = g_lab_rstats;
+#endif
     const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_EXT");
     hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
 }

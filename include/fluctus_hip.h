@@ -224,7 +224,11 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *   xcd_remap, eager_bump: A/B knobs of the binary kernels */
 int flx_set_option(flx_ctx *ctx, const char *name, int value);
 /* current value of an option above, or of the read-only "fused_queue_mask" (bit q set = the fused pass inlines the material step of
- * queue q's paths, flx_queue_counters order) */
+ * queue q's paths, flx_queue_counters order), or of the read-only "phase": the state of the call-sequence state machine behind the
+ * deferred / fused / early-started kernels (api.hip: enum Phase) -- bits 0-2: 0 idle, 1 flx_wf_logic deferred, 2 flx_wf_logic +
+ * flx_wf_raygen deferred, 3 only genRays / material kernels enqueued since logic, 4 ... and the extension kernel last, 5 the extension
+ * kernel last with the chain since logic broken; bit 3: the hit records of the last extension launch are still RAW; bit 4: the material
+ * queues are known to be empty.  Never changes any state (tests/test_gpu_fuzz.py reports its coverage with it). */
 int flx_get_option(flx_ctx *ctx, const char *name, int *value);
 
 #ifdef __cplusplus

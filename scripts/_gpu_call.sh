@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py -q -x -s -k "arithmetic_contract" 2>&1 | grep -v "^$" | tail -15 > gpurun_out/r04_fork.log
-timeout 1500 python -m pytest tests/test_gpu_wide.py -q -x -s -k "bench_launch_chain" 2>&1 | grep -v "^$" | grep -E "fork|passed|failed|Error" >> gpurun_out/r04_fork.log
-cat gpurun_out/r04_fork.log; cat gpurun_out/r04_wide_flips.json | tail -30
+timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -x -s 2>&1 | grep -v "^$" | tail -12 > gpurun_out/r04_fuzz.log
+cat gpurun_out/r04_fuzz.log
+bash scripts/gpu_validate.sh r04a

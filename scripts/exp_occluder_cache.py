@@ -16,6 +16,16 @@ from fluctus_amd.wire import COL, Q  # noqa: E402
 from oracle.binding import OracleContext  # noqa: E402
 
 
+def analysis_lib():
+    """tests/_build/libwide_analysis.so (tests/wide_analysis.cpp; built by tests/conftest.py: build_wide_analysis)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    L = C.CDLL(conftest.build_wide_analysis())
+    L.fh_analysis_last_error.restype = C.c_char_p
+    return L
+
+
+
 def mt_hit(o, d, tmax, p0, p1, p2):
     s1, s2 = p1 - p0, p2 - p0
     pv = np.cross(d, s2); det = (s1 * pv).sum(1)
@@ -38,7 +48,7 @@ def main():
     c.upload_scene(d); c.upload_envmap(env); c.set_params(p); driver.reset_renderer(c)
     npix = int(p["width"]) * int(p["height"])
     P = np.stack([np.stack([d.tris[v]["p"][k] for k in "xyz"], -1) for v in ("v0", "v1", "v2")], 1).astype(np.float32)      # ntris x 3 x 3
-    L = host.lib()
+    L = analysis_lib()
     mode = 2 if (p["useEnvMap"] and not p["useAreaLight"]) else 1
     cache = np.full(n, -1, np.int64)
     tot = dict(rays=0, occluded=0, cached=0, cache_hit=0, visits=0.0, visits_saved=0.0)

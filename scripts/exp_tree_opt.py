@@ -16,6 +16,16 @@ from fluctus_amd.wire import COL, Q  # noqa: E402
 from oracle.binding import OracleContext  # noqa: E402
 
 
+def analysis_lib():
+    """tests/_build/libwide_analysis.so (tests/wide_analysis.cpp; built by tests/conftest.py: build_wide_analysis)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest
+    L = C.CDLL(conftest.build_wide_analysis())
+    L.fh_analysis_last_error.restype = C.c_char_p
+    return L
+
+
+
 def steady_rays(d, p, env, n=1 << 16, iters=14):
     c = OracleContext(n, threads=os.cpu_count())
     c.upload_scene(d); c.upload_envmap(env); c.set_params(p); driver.reset_renderer(c)
@@ -35,21 +45,21 @@ def steady_rays(d, p, env, n=1 << 16, iters=14):
 
 
 def visits(d, nodes, rays, mode):
-    L = host.lib()
+    L = analysis_lib()
     out = np.zeros(8, np.float64)
     rc = L.fh_wide_visits(nodes.ctypes.data_as(C.c_void_p), C.c_uint64(nodes.size), d.tris.ctypes.data_as(C.c_void_p), C.c_uint64(d.tris.size),
                           d.indices.ctypes.data_as(C.c_void_p), C.c_uint64(d.indices.size), rays.ctypes.data_as(C.c_void_p), C.c_uint64(rays.shape[0]), mode,
                           out.ctypes.data_as(C.c_void_p))
-    assert rc == 0, L.fh_last_error()
+    assert rc == 0, L.fh_analysis_last_error()
     return out
 
 
 def optimise(nodes, passes):
-    L = host.lib()
+    L = analysis_lib()
     out = np.zeros_like(nodes); st = np.zeros(8, np.float64)
     t0 = time.time()
     rc = L.fh_wide_optimise(nodes.ctypes.data_as(C.c_void_p), C.c_uint64(nodes.size), passes, out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
-    assert rc == 0, L.fh_last_error()
+    assert rc == 0, L.fh_analysis_last_error()
     return out, st, time.time() - t0
 
 

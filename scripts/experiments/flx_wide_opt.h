@@ -1,3 +1,9 @@
+// ARCHIVED EXPERIMENT (round 4; not part of the product: built only into tests/_build/libwide_analysis.so for scripts/exp_tree_opt.py).
+// Measured on the device (profiles/r04_wide_opt_ab.txt, two passes): node visits per closest-hit ray 10.64 -> 10.55 kitchen, 11.74 -> 11.12
+// conference, 25.99 -> 25.64 courtyard; k_trace4r -0.7 % / -3 % / 0 %, k_shadow4 -2.5 % / -3 % / -1.4 %, step +0.4 % / +0.5..3 % / +-0; upload +0.75 s /
+// +0.25 s / +25 s.  The round-3 verdict asked for -8 % visits on kitchen AND courtyard: the reference builder's SBVH topology is already within a
+// few per cent of what reinsertion finds.  Not shipped.
+//
 // flx_wide_opt.h -- re-optimisation of the INNER topology of the traversal tree before it is collapsed into 4-wide nodes (flx_wide.h).
 //
 // WHY.  Both traversal kernels are VALU-issue-bound and pay ~140 VALU instructions per wide-node visit, so the lever that is
@@ -25,6 +31,7 @@
 #include <algorithm>
 #include <cstring>
 #include "../../include/fluctus_wire.h"
+#include "../../fluctus_amd/csrc/flx_wide.h"
 
 namespace flxw {
 
@@ -191,6 +198,47 @@ static inline bool optimise_topology(const flx_node *nodes, size_t nnodes, int p
     }
     out.swap(res);
     return true;
+}
+
+// Slot order inside a wide node.  The closest-hit query sorts the hit children by entry distance and the far -> near any-hit order does too,
+// so for them the slot order is irrelevant; the any-hit order "LAST hit slot first, earlier hits pushed" (flx_trace4.h: ANY_ORDER 0, rays toward
+// an area light) descends in SLOT order.  The answer is the same whatever the order (any hit), the number of nodes visited before the first
+// occluder is not: putting the child that is most likely to hold an occluder LAST makes it the one taken first.  key: 1 = surface area of the
+// child's box (ascending), 2 = number of triangles below the child (ascending), 3 = triangles per unit area (ascending), 0 = leave as built.
+// Slots are permuted in place (references and the six plane bytes of each slot); empty slots stay behind the used ones.
+static inline void reorder_slots(WideTree &w, int key)
+{
+    if (key <= 0 || (w.rootRef & FLX_WIDE_LEAF_BIT) || w.nodes.empty()) return;
+    const size_t n = w.nodes.size();
+    std::vector<double> tris(n, 0.0);
+    auto slot_ref = [](const WNode &nd, int c) { return c == 0 ? nd.c0 : c == 1 ? nd.c1 : c == 2 ? nd.c2 : nd.c3; };
+    auto byte = [](uint32_t v, int c) { return (v >> (8 * c)) & 255u; };
+    for (size_t i = n; i-- > 0;) {                                         // children are numbered after their parent
+        WNode &nd = w.nodes[i];
+        double cnt[4], area[4]; uint32_t refs[4]; int used = 0;
+        for (int c = 0; c < 4; c++) {
+            refs[c] = slot_ref(nd, c);
+            cnt[c] = 0.0; area[c] = 0.0;
+            if (refs[c] == FLX_WIDE_EMPTY) continue;
+            used = c + 1;
+            if (refs[c] & FLX_WIDE_LEAF_BIT) { int k; memcpy(&k, &w.leafdata[refs[c] & FLX_WIDE_OFF_MASK].w, 4); cnt[c] = k; }
+            else cnt[c] = tris[refs[c]];
+            const double ex = (double)(byte(nd.qhix, c) - (double)byte(nd.qlox, c)) * nd.sx, ey = (double)(byte(nd.qhiy, c) - (double)byte(nd.qloy, c)) * nd.sy,
+                         ez = (double)(byte(nd.qhiz, c) - (double)byte(nd.qloz, c)) * nd.sz;
+            area[c] = ex * ey + ey * ez + ez * ex;
+            tris[i] += cnt[c];
+        }
+        int perm[4] = {0, 1, 2, 3};
+        auto val = [&](int c) { return key == 1 ? area[c] : key == 2 ? cnt[c] : (area[c] > 0.0 ? cnt[c] / area[c] : 1e300); };
+        std::stable_sort(perm, perm + used, [&](int a, int b) { return val(a) < val(b); });
+        uint32_t q[6] = {nd.qlox, nd.qloy, nd.qloz, nd.qhix, nd.qhiy, nd.qhiz}, qn[6] = {0, 0, 0, 0, 0, 0}, rn[4];
+        for (int c = 0; c < 4; c++) {
+            rn[c] = refs[perm[c]];
+            for (int k = 0; k < 6; k++) qn[k] |= byte(q[k], perm[c]) << (8 * c);
+        }
+        nd.c0 = rn[0]; nd.c1 = rn[1]; nd.c2 = rn[2]; nd.c3 = rn[3];
+        nd.qlox = qn[0]; nd.qloy = qn[1]; nd.qloz = qn[2]; nd.qhix = qn[3]; nd.qhiy = qn[4]; nd.qhiz = qn[5];
+    }
 }
 
 } // namespace flxw

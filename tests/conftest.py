@@ -18,6 +18,22 @@ def _built():
     import __graft_entry__ as g
     g.build_cpu_libs()
     build_fake_rccl()
+    build_wide_analysis()
+
+
+def build_wide_analysis(force=False):
+    """Test / experiment infrastructure only: tests/wide_analysis.cpp -> tests/_build/libwide_analysis.so (host emulation of the 4-wide traversal on
+    the product's own tree builder; tests/test_wide_emulation.py, scripts/exp_tree_opt.py, scripts/exp_occluder_cache.py)."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "wide_analysis.cpp")
+    deps = [src, os.path.join(ROOT, "fluctus_amd", "csrc", "flx_wide.h"), os.path.join(ROOT, "scripts", "experiments", "flx_wide_opt.h"),
+            os.path.join(ROOT, "include", "flx_math.h"), os.path.join(ROOT, "include", "fluctus_wire.h")]
+    out = os.path.join(ROOT, "tests", "_build", "libwide_analysis.so")
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", src, "-o", out], check=True)
+    return out
 
 
 def build_fake_rccl(force=False):
