@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): the kitchen-class scene at 1920x1080, 8 bounces, env-map MIS, separate
 material queues.  Country-Kitchen.obj is a missing blob in the reference checkout, so the scene is the
 deterministic procedural stand-in "kitchen-proc" (~0.5 M triangles, the real .mtl's material-type mix,
-SURVEY 8(d)) with a synthetic HDR sky; SBVH built by the host library.  NUM_TASKS = 4 194 304 paths in flight per
+SURVEY 8(d)) with a synthetic HDR sky; SBVH built by the host library.  NUM_TASKS = 8 388 608 paths in flight per
 GPU (the reference's `wfBufferSize` setting, re-tuned for this chip -- see the comment at NUM_TASKS).
 
 A step = one benchmark-style iteration of the reference's runBenchmark body (src/tracer.cpp:433-439):
@@ -30,10 +30,13 @@ import numpy as np  # noqa: E402
 WIDTH, HEIGHT, BOUNCES = 1920, 1080, 8
 # Paths in flight per GPU.  The reference's knob is the `wfBufferSize` setting (src/settings.cpp:20 "appropriate for dedicated GPU",
 # 1e6 in settings_default.json, i.e. sized for a GTX-class part); an MI355X holds 458 k lanes at once, so 1 M paths is only 2.3 per
-# lane and the traversal kernels spend much of their time in the tail.  Measured on kitchen-proc 1080p: 1 M 2762, 2 M 3027,
-# 4 M 3188, 8 M 3117-3212 Mrays/s (roofline.frac 0.61 / 0.74 / 0.81 / 0.86); beyond 4 M the path state (204 B/path) no longer fits
-# the 256 MB Infinity Cache and the cheaper scenes lose (conference: 3325 at 1 M, 3121 at 8 M).
-NUM_TASKS = 1 << 22
+# lane and the traversal kernels spend much of their time in their tails.  Round 1 (kitchen-proc 1080p): 1 M 2762, 2 M 3027, 4 M 3188 Mrays/s.
+# Round 4, same box, 4 M / 6 M / 8 M / 16 M (profiles/r04_num_tasks.txt): kitchen 5207 / 5417 / 5488 / 5297, conference 5146 / 5290 / 5388 /
+# 5351, courtyard-1440p 2245 / 2368 / 2434 / 2480 -- with the persistent closest-hit kernel and the fused pass every launch has a fixed
+# tail and seven dependent launches per iteration have their gaps, and 8 M paths amortise both (+5 % / +5 % / +8 %); 16 M loses again on the
+# scenes whose tree lives in the Infinity Cache (3.3 GB of path state stream through it per iteration).  8 M paths = 1.6 GB of state +
+# 0.3 GB of queues per GPU of 288 GB.
+NUM_TASKS = 1 << 23
 TARGET_TRIS, SCENE_SEED = 500000, 42
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 

@@ -318,13 +318,14 @@ def test_default_path_2160p_checkpoint_vs_oracle():
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
-def test_default_path_4M_checkpoint_vs_oracle():
-    """The bench's OWN path count: every other device-vs-ORACLE run is 1 M paths, bench.py times 4 M (other grid sizes, cursor traffic,
-    persistent-grid : block ratio).  kitchen at n = 1 << 22: the device runs 20 iterations alone (stationary queue mix, deep paths in
-    flight), then two whole iterations in lockstep with the oracle, ray by ray as above."""
-    n = 1 << 22
+def test_default_path_bench_path_count_checkpoint_vs_oracle():
+    """The bench's OWN path count: every other device-vs-ORACLE run is 1 M paths, bench.py times bench.NUM_TASKS = 8 M (other grid sizes, cursor
+    traffic, persistent-grid : block ratio, a second level of the scan).  kitchen at n = bench.NUM_TASKS: the device runs 20 iterations alone
+    (stationary queue mix, deep paths in flight), then two whole iterations in lockstep with the oracle, ray by ray as above."""
+    import bench
+    n = bench.NUM_TASKS
     rays, flips = _free_run_default_vs_oracle("kitchen", n, 2, start_iterations=20)
-    _report("default_4M_checkpoint_kitchen", {"paths": n, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips})
+    _report("default_bench_path_count_checkpoint_kitchen", {"paths": n, "extension_rays_compared_vs_oracle": rays, "hit_index_flips": flips})
     assert rays == 2 * n and flips <= FLIP_BUDGET * rays, (rays, flips)
 
 
