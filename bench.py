@@ -514,6 +514,9 @@ def main():
                 "frac_alone": (ach * launch_s / alone_s / HBM_PEAK_GBS) if (ach is not None and alone_s > 0 and launch_s > 0) else None,
                 "launch_ms": launch_s * 1e3, "launch_ms_alone": alone_s * 1e3,
                 "own_bytes_per_ray": own_bytes_per_ray,
+                # bytes the RUNNING kernel touches per ray (own node / leaf / triangle counters) over the launch time: L1 / L2 / Infinity-Cache hits
+                # included, so it is a touch rate, not memory traffic -- it exceeds the HBM peak on a cache-resident tree (that is the point of the cache)
+                "own_touched_GBps": (own_bytes / launch_s / 1e9) if (own_bytes and launch_s > 0) else None,
                 "frac_own": (own_bytes / launch_s / 1e9 / HBM_PEAK_GBS) if (own_bytes and launch_s > 0) else None,
                 "own_avg_wide_node_visits": (st_own["ext_inner"] / max(1, st_own["ext_rays"])) if own_leaf is not None else None,
                 "own_avg_leaf_visits": (own_leaf["ext_leaf"] / max(1, st_own["ext_rays"])) if own_leaf is not None else None,

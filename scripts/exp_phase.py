@@ -74,7 +74,7 @@ def main():
     d, p, env = bench.build_workload(name=workload)
     torch.cuda.init()
     single = [make(d, p, env, total, 0, 1)]
-    for rep in range(2):
+    for rep in range(0 if os.environ.get("FLX_PHASE_SKIP_SINGLE") else 2):
         v, ms = run(single, None, False, 30, 24)
         print(f"{workload} {total} paths  single          {v:7.0f} Mrays/s  {ms:.3f} ms/step", flush=True)
     single[0].close()

@@ -16,6 +16,11 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
     shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
 KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
         "k_queue_scatter", "k_queue_scan")
+bench = {}
+try:
+    bench = json.loads(open(os.path.join(prof, f"{tag}_{wl}_bench.json")).readline())
+except Exception:
+    pass
 # Steady state only: the first `settle_iterations` dispatches of every kernel are the transient from reset (iteration 0 traces nothing but
 # primary rays) and are dropped; what is averaged is the timed window + the extra untimed passes over the same steady state.
 skip = int(bench.get("settle_iterations", 0))
