@@ -11,7 +11,8 @@ The hand-picked call patterns of tests/test_gpu_wide.py::test_raw_hit_records_ca
 draws >= 300 sequences of up to 12 calls over
     {logic(first), raygen, materials, extend, shadow, clear_queues, get_counters, finish, set_params, state_export, queue_read,
      set_option(fuse | refill_extend | extend_tree | fuse_set | overlap), pixel_index_update, end_iteration}
-(kept inside what the reference's queues can hold: logic once, genRays and the material kernels at most once per clear), runs each on
+(kept inside what the reference itself defines: its queues hold NUM_TASKS entries -- logic once, genRays and the material kernels at most once
+per clear -- and the microkernel integrator is not mixed in: on wavefront state it indexes materials[-1] in the reference's own kernels), runs each on
 the device and on the oracle from a synchronised state, and compares the whole path state, all eight queues and the counters after every
 sequence -- and at every observation inside one.  No RAW marker may ever be exported.  Coverage is reported as the set of
 (phase before, call) pairs of the explicit state machine (flx_get_option "phase") that were exercised.
