@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--shadow-tree", type=int, default=4, choices=(2, 4))
     ap.add_argument("--overlap", type=int, default=-1, help="stream schedule of the two traversals: 0 serial, 1 shadow beside extension, 2 shadow right after logic, -1 = what flx_upload_scene picks for the scene")
     ap.add_argument("--fuse", type=int, default=1, choices=(0, 1), help="logic + material kernels as one fused pass (default) or the separate kernels")
-    ap.add_argument("--ext-order", type=int, default=-1, choices=(-1, 0, 1), help="fused pass: extension queue lists the continuing paths by path id (1) or in one segment per material queue (0); -1 = what flx_upload_scene chose")
+    ap.add_argument("--ext-order", type=int, default=-1, choices=(-1, 0, 1, 2), help="fused pass: extension queue lists the continuing paths by path id (1) or in one segment per material queue (0); -1 = what flx_upload_scene chose")
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
     ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")

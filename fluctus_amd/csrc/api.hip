@@ -28,7 +28,7 @@ void launch_materials_after_fused(hipStream_t, const State &, const Queues &, co
 uint32_t fused_queue_mask(int);
 uint32_t logic_aux_stride(uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
-void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
+void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &, int);
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
 void launch_state_export(hipStream_t, const State &, float *, float);
 void launch_state_import(hipStream_t, const State &, const float *);
@@ -67,7 +67,7 @@ struct flx_ctx {
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
     // takes one step of the state machine first (enter()), so no call ever observes a state the separate kernels would not have produced.
     int fuse = 1;
-    int extOrder = 0;                           // fused pass: extension queue lists the continuing paths 1 by path id | 0 one segment per material queue; chosen at flx_upload_scene
+    int extOrder = 0;                           // fused pass: extension queue lists the continuing paths 1 by path id | 2 merged with the regenerated ones by path id | 0 one segment per material queue; chosen at flx_upload_scene
     int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 31 all six; chosen at flx_upload_scene
     int pendFirst = 0;                          // the deferred flx_wf_logic's `first` (phases PH_DEFER_*)
     bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
@@ -410,7 +410,10 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         // path id: conference 4318 -> 4446 (+3 %: three BSDF types of similar weight, the segments cut the id order into thirds),
         // kitchen 4278 -> 4230, courtyard 1678 -> 1652 (one dominant type: its segment IS the id order, and the small segments of the
         // other types are rays leaving the same few objects).  Option "ext_order" overrides.
-        c->extOrder = c->fuseSet == 31 ? 1 : 0;
+        // Round 4, 8 M paths (profiles/r04_ext_order_ab.txt, same box): with the diffuse-only pass the kitchen's closest-hit kernel takes 1.056 ms on
+        // the per-queue segments, 1.037 by path id, 1.035 with the regenerated paths merged in (ext_order 2: the queue is the identity permutation in
+        // the steady state; step +1 %); conference and courtyard (all-types pass) do not move between 1 and 2.  Hence 2 with the diffuse-only pass.
+        c->extOrder = c->fuseSet == 31 ? 1 : 2;
     }
 
     // 1. leaf triangle records, in index-list order (a leaf is a contiguous run of the list)
@@ -622,10 +625,10 @@ int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); { ScopedTime
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
 static void flushExtIfPending(flx_ctx *c, uint32_t bits) { if (c->qs.extPend & bits) flushExt(c); }
-static int runRaygen(flx_ctx *c)
+static int runRaygen(flx_ctx *c, int appendExt = 1)
 {
     flushExtIfPending(c, 1u << FLX_Q_RAYGEN);
-    { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params); }
+    { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params, appendExt); }
     c->qs.extPend |= 1u << FLX_Q_RAYGEN;
     if (c->eagerBump) flushExt(c);
     LAUNCHED(c);
@@ -641,6 +644,10 @@ static int materialise(flx_ctx *c)
     LAUNCHED(c);
     return 0;
 }
+// how this fused pass lists the traced paths in the extension queue: ext_order 2 (regenerated + continuing paths merged by path id) needs
+// genRays to follow in the same chain -- the scatter writes the regenerated paths' entries, genRays then must not -- and falls back to 1
+// (continuing paths by id, genRays appends its own block whenever it is called) otherwise
+static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && !raygenFirst) ? 1 : c->extOrder; }
 static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
     // RAW hit records are committed by the fused pass itself when genRays follows in the same chain (logic.hip: k_logic<FUSE, RAW>); the plain
@@ -651,7 +658,7 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     if (!raw && materialise(c)) return 1;
     c->rawHits = false;
     flushExt(c);                                       // logic's scan overwrites the source-queue counters
-    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, c->extOrder, raw); }
+    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, extOrderFor(c, fused, raygenFirst), raw); }
     LAUNCHED(c);
     c->matQueuesEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -774,10 +781,11 @@ int flx_wf_materials(flx_ctx *c)
         ENTER(c, CALL_MATERIALS);
         NEED(c, c->haveParams && c->sc.bnodes, "set params and upload a scene first");
         HIPCHK(c, hipSetDevice(c->device));
+        const int order = extOrderFor(c, c->fuseSet, withRaygen);
         if (runLogic(c, c->pendFirst, c->fuseSet, withRaygen)) return 1;
-        if (withRaygen && runRaygen(c)) return 1;
+        if (withRaygen && runRaygen(c, order == 2 ? 0 : 1)) return 1;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
-        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), c->extOrder); }
+        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), order); }
         LAUNCHED(c);
         c->qs.extPend |= materialBits(c);
         if (c->eagerBump) flushExt(c);
@@ -1277,7 +1285,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     ENTER(c, CALL_PEEK);
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
-    if (name && strcmp(name, "ext_order") == 0 && (value == 0 || value == 1)) { c->extOrder = value; return 0; }
+    if (name && strcmp(name, "ext_order") == 0 && value >= 0 && value <= 2) { c->extOrder = value; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { ENTER(c, CALL_OBSERVE); c->overlapOpt = value; pickSchedule(c); return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { ENTER(c, CALL_OBSERVE); c->shadowTree = value; return 0; }

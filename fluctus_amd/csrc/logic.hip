@@ -394,7 +394,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
             for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w];
             r += mbcnt(bal[l]);
             outq[l][r] = gid;
-            if (fuse != 0 && !byPathId && l >= 2 && fuse_inlines_list(fuse, (uint32_t)(l - 1))) {
+            if (fuse != 0 && byPathId == 0u && l >= 2 && fuse_inlines_list(fuse, (uint32_t)(l - 1))) {
                 // option ext_order 0: the separate kernels' order -- one segment per material queue; the types that are not inlined
                 // are appended by their material kernel
                 uint32_t base = ext_len(qs) + (raygenFirst ? qs.counters[FLX_Q_RAYGEN] : 0u);
@@ -403,12 +403,23 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
             }
         }
     }
-    if (fuse != 0 && byPathId && ml != 0u) {
+    if (fuse != 0 && byPathId == 1u && ml != 0u) {
         // the continuing paths of ALL material lists, in path-id order (see the comment above the kernel)
         uint32_t r = s_off[2] + s_off[3] + s_off[4] + s_off[5] + s_off[6];
         for (uint32_t w = 0; w < wave; w++) r += s_cnt[2][w] + s_cnt[3][w] + s_cnt[4][w] + s_cnt[5][w] + s_cnt[6][w];
         r += mbcnt(bal[2] | bal[3] | bal[4] | bal[5] | bal[6]);
         qs.q[FLX_Q_EXTENSION][ext_len(qs) + (raygenFirst ? qs.counters[FLX_Q_RAYGEN] : 0u) + r] = gid;
+    }
+    if (fuse != 0 && byPathId == 2u && ((member & 1u) != 0u || ml != 0u)) {
+        // ext_order 2: EVERY path that will be traced -- the regenerated ones (genRays follows in this chain and does not append: k_raygen,
+        // appendExt 0) merged with the continuing ones -- as ONE list in path-id order.  In the steady state every path traces an extension
+        // ray, so the queue is the identity permutation: the traversal kernel's path-state accesses are fully coalesced (round 3 measured
+        // -2 % / -2 % / -6 % of the closest-hit kernel for that order on host-reordered queues, scripts/exp_ray_order.py).  The same SET as the
+        // separate kernels' [regenerated | material segments] (the reference's order is whatever its atomic_inc produces).
+        uint32_t r = s_off[0] + s_off[2] + s_off[3] + s_off[4] + s_off[5] + s_off[6];
+        for (uint32_t w = 0; w < wave; w++) r += s_cnt[0][w] + s_cnt[2][w] + s_cnt[3][w] + s_cnt[4][w] + s_cnt[5][w] + s_cnt[6][w];
+        r += mbcnt(bal[0] | bal[2] | bal[3] | bal[4] | bal[5] | bal[6]);
+        qs.q[FLX_Q_EXTENSION][ext_len(qs) + r] = gid;
     }
 }
 

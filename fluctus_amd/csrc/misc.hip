@@ -48,7 +48,9 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame
     if (gid == 0) qs.counters[FLX_Q_RAYGEN] = st.numTasks;
 }
 
-__global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p)
+// appendExt 0: the extension-queue entries of the regenerated paths were written already -- by the fused scatter, merged with the continuing
+// paths into ONE list in path-id order (logic.hip: k_queue_scatter, ext_order 2) -- and only the paths are regenerated here
+__global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p, uint32_t appendExt)
 {
     const uint32_t qlen = qs.counters[FLX_Q_RAYGEN];
     // capped grid striding over the queue (its length is only known here; see MAT_GRID in material.hip)
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         st.pickProb[gid] = 1.0f;                                       // read by the MIS weights before any NEE may have written it
         st.blocked[gid] = 1u;
         st.firstDiffuse[gid] = 0u;
-        qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;              // extBase + index (see flx_device.h)
+        if (appendExt) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;              // extBase + index (see flx_device.h)
     }
 }
 
@@ -236,11 +238,11 @@ void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame 
     uint32_t n = st.numTasks > fr.localPixels ? st.numTasks : fr.localPixels;      // src/clcontext.cpp:767
     hipLaunchKernelGGL(k_reset, dim3((n + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, n);
 }
-void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p)
+void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p, int appendExt)
 {
     uint32_t blocks = (st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK;
     if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, (uint32_t)appendExt);
 }
 void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
 {

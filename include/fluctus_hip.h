@@ -216,9 +216,11 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     (or a build that inlines every type) -- otherwise, and with 0, every call launches its own kernels at once
  *   fuse_set          BSDF types the fused pass inlines: 1 diffuse only | 31 all six.  flx_upload_scene picks it from the scene
  *                     (diffuse surfaces >= 3/4 of the triangle area: 1, else 31); set it after the upload to override
- *   ext_order         how the fused pass lists the continuing paths in the extension queue: 0 one segment per material queue, in the
- *                     separate kernels' order | 1 all of them by path id (the same SET of paths either way; the reference's order is
- *                     whatever its atomic_inc produces).  flx_upload_scene picks it with fuse_set (1 with 31); set it afterwards to override
+ *   ext_order         how the fused pass lists the traced paths in the extension queue: 0 one segment per material queue, in the
+ *                     separate kernels' order | 1 all continuing paths by path id | 2 continuing AND regenerated paths merged into one
+ *                     list by path id (genRays then does not append; needs genRays between logic and the material kernels, else as 1).
+ *                     The same SET of paths either way; the reference's order is whatever its atomic_inc produces.  flx_upload_scene picks
+ *                     it with fuse_set (1 with 31, 2 with 1); set it afterwards to override
  *   node_layout       1 (default) sibling-pair record numbering of the binary tree | 0 DFS numbering; takes effect at the next flx_upload_scene
  *   denoiser          1: accumulate the denoiser feature buffers (see flx_read_pixels); default 0
  *   xcd_remap, eager_bump: A/B knobs of the binary kernels */

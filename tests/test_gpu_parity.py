@@ -15,7 +15,7 @@ from fluctus_amd import host, wire, driver
 pytestmark = pytest.mark.gpu
 
 
-TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_set": 0}
+TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_set": 0, "ext_order": -1}
 
 
 # (extend_tree, shadow_tree, xcd_remap, overlap): every tree / stream schedule that claims bit-exactness must give the same bits.
@@ -25,12 +25,14 @@ TRACE_MODE = {"ext": 2, "shadow": 4, "xcd": 0, "overlap": 2, "fuse": 1, "fuse_se
 # default; api.hip) vs always the separate kernels.
 # fuse_set: the BSDF types that pass inlines -- 0 = what flx_upload_scene picked for the scene, 1 diffuse only (the rest through their
 # queues), 31 all.
-@pytest.fixture(params=[(2, 4, 0, 2, 1, 0), (2, 2, 1, 1, 1, 31), (2, 2, 0, 0, 0, 0), (2, 4, 0, 0, 1, 1), (2, 4, 0, 1, 0, 0)],
+# ext_order: -1 = what the suite always used (1 with fuse_set 31, else 0 / the scene's), 2 = regenerated + continuing paths merged by path id.
+@pytest.fixture(params=[(2, 4, 0, 2, 1, 0, -1), (2, 2, 1, 1, 1, 31, -1), (2, 2, 0, 0, 0, 0, -1), (2, 4, 0, 0, 1, 1, -1), (2, 4, 0, 1, 0, 0, -1), (2, 4, 0, 2, 1, 31, 2),
+                        (2, 4, 0, 2, 1, 1, 2)],
                 ids=["wide-shadow", "binary-shadow-xcdremap-overlap1-fuseall", "binary-shadow-serial-unfused", "wide-shadow-serial-fusediffuse",
-                     "wide-shadow-overlap1-unfused"], autouse=True)
+                     "wide-shadow-overlap1-unfused", "wide-shadow-fuseall-merged-queue", "wide-shadow-fusediffuse-merged-queue"], autouse=True)
 def trace_mode(request):
     (TRACE_MODE["ext"], TRACE_MODE["shadow"], TRACE_MODE["xcd"], TRACE_MODE["overlap"], TRACE_MODE["fuse"],
-     TRACE_MODE["fuse_set"]) = request.param
+     TRACE_MODE["fuse_set"], TRACE_MODE["ext_order"]) = request.param
     yield
 
 
@@ -51,7 +53,7 @@ def _ctxs(d, p, n, env=None):
         driver.reset_renderer(c)
     if TRACE_MODE["fuse_set"]:
         g.set_option("fuse_set", TRACE_MODE["fuse_set"])          # after the upload, which picks one for the scene
-        g.set_option("ext_order", 1 if TRACE_MODE["fuse_set"] == 31 else 0)
+        g.set_option("ext_order", TRACE_MODE["ext_order"] if TRACE_MODE["ext_order"] >= 0 else (1 if TRACE_MODE["fuse_set"] == 31 else 0))
     return g, o
 
 
@@ -68,6 +70,10 @@ def _compare(g, o, what, check_queues=True, ext_set=False):
                 # per material queue: the same SET (the reference's own order is whatever its atomic_inc produces), the regenerated
                 # paths' block where the call order puts it
                 assert np.array_equal(np.sort(qa), np.sort(qb)), f"{what}: extension queue holds different paths"
+                if g.get_option("ext_order") == 2 and (ext_set == "merged" or (ext_set != "blocks" and n > 1 and (np.diff(qa.astype(np.int64)) > 0).all())):
+                    # ext_order 2 with genRays between logic and the material kernels: regenerated and continuing paths as ONE list in path-id order
+                    assert (np.diff(qa.astype(np.int64)) > 0).all(), f"{what}: merged extension queue not in path-id order"
+                    continue
                 r = int(co[Q.RAYGEN])
                 regen = o.queue_read(Q.RAYGEN)[:r]
                 if r and n > r and np.array_equal(qb[:r], regen):              # genRays was enqueued before the material kernels
@@ -113,8 +119,10 @@ def _lockstep_iterations(g, o, npix, iters, order=("logic", "raygen", "materials
             c.clear_queues()                        # the state sync above rewrote the counters: the queues are empty, say so
             for name in order:
                 fns[name](c)
-        fused_now = bool(TRACE_MODE["fuse"] and (separate_queues or g.get_option("fused_queue_mask") == 0xF8)) and g.get_option("ext_order") == 1
-        _compare(g, o, f"it{it} {'+'.join(order)}", ext_set=fused_now)
+        fused_now = bool(TRACE_MODE["fuse"] and (separate_queues or g.get_option("fused_queue_mask") == 0xF8)) and g.get_option("ext_order") >= 1
+        # ext_order 2 merges the regenerated paths in only when genRays sits between logic and the material kernels (api.hip: extOrderFor)
+        merged = fused_now and g.get_option("ext_order") == 2 and tuple(order) == ("logic", "raygen", "materials")
+        _compare(g, o, f"it{it} {'+'.join(order)}", ext_set=("merged" if merged else fused_now))
         cnt = o.get_counters().copy()
         for c in (g, o):
             c.wf_extend(); c.wf_shadow()
@@ -201,7 +209,7 @@ def test_deferred_logic_call_patterns():
         g.profile_enable(1); g.profile_reset()
         seq(g); seq(o)
         want = fused_passes if TRACE_MODE["fuse"] else 0
-        _compare(g, o, name, ext_set=bool(want) and g.get_option("ext_order") == 1)
+        _compare(g, o, name, ext_set=bool(want) and g.get_option("ext_order") >= 1)
         prof = g.profile_get(); g.profile_enable(0)
         assert prof["logic_fused"][1] == want, (name, prof)
         for c in (g, o):

@@ -8,7 +8,7 @@ from fluctus_amd import host, driver
 pytestmark = pytest.mark.gpu
 
 ITERS = 150
-CONFIGS = [(0, 0, 0), (1, 1, 0), (1, 31, 1), (1, 1, 1), (1, 31, 0)]          # (fuse, fuse_set, ext_order)
+CONFIGS = [(0, 0, 0), (1, 1, 0), (1, 31, 1), (1, 1, 1), (1, 31, 0), (1, 31, 2), (1, 1, 2)]          # (fuse, fuse_set, ext_order)
 
 
 @pytest.mark.parametrize("flags", [dict(useAreaLight=1, useEnvMap=1, wfSeparateQueues=1),
