@@ -147,6 +147,8 @@ def cpu_baseline(d, p, env, budget_s=12.0, force_kind=None):
     container (oracle/ref/Makefile), their NDRanges spread over the usable cores in chunks of 64 work-items the way a CPU
     OpenCL device schedules work-groups.  kind "port" (fallback when that library is absent): oracle/wf_oracle.cpp."""
     from fluctus_amd import driver
+    from oracle import build as oracle_build
+    oracle_build.build_all()
     from oracle.binding import OracleContext, RefContext, ref_available
     cores = usable_cores()
     n = 1 << 16
@@ -201,7 +203,7 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
-    entry.build_cpu_libs()
+    entry.build_product()             # the checker (oracle/) is built by cpu_baseline(), the only leg that uses it
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

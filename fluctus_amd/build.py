@@ -1,5 +1,5 @@
-"""In-tree builds (no JIT caches): libfluctus_hip.so (hipcc, gfx950), libfluctus_host.so (g++),
-oracle/liboracle.so (g++), oracle/_ref (only where /root/reference exists)."""
+"""In-tree builds of the PRODUCT (no JIT caches): libfluctus_hip.so (hipcc, gfx950) and libfluctus_host.so (g++).
+The checker (oracle/) has its own build entry, oracle/build.py; nothing here knows about it."""
 import glob
 import os
 import subprocess
@@ -42,25 +42,6 @@ def build_host(force=False):
     return out
 
 
-def build_oracle(force=False):
-    src = [os.path.join(ROOT, "oracle", "wf_oracle.cpp")]
-    out = os.path.join(ROOT, "oracle", "liboracle.so")
-    if force or _stale(out, src + _headers()):
-        _run(["g++"] + CXX_FLAGS + ["-ffp-contract=off", "-fopenmp"] + src + ["-o", out])
-    return out
-
-
-def build_ref(force=False):
-    """The reference's own kernels for x86-64 -- only where the reference checkout exists (this container)."""
-    if not os.path.isdir("/root/reference/src"):
-        return None
-    out = os.path.join(ROOT, "oracle", "_ref", "libfluctus_ref.so")
-    dep = glob.glob(os.path.join(ROOT, "oracle", "ref", "*"))
-    if force or _stale(out, dep):
-        _run(["make", "-C", os.path.join(ROOT, "oracle", "ref"), "-j8"])
-    return out
-
-
 def build_hip(force=False):
     src = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
     dep = src + glob.glob(os.path.join(PKG, "csrc", "*.h")) + _headers()
@@ -91,6 +72,6 @@ def build_all(force=False):
     with open(os.path.join(PKG, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return [build_hip(force), build_host(force), build_oracle(force), build_ref(force)]
+            return [build_hip(force), build_host(force)]
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)

@@ -167,7 +167,7 @@ def sync(dst, src):
     if hasattr(src, "finish"):
         src.finish()
     cnt = np.array(cnt, copy=True)
-    for q in range(Q.NUM - 1):
+    for q in range(Q.NUM):                          # all eight (until round 5 this loop stopped before the delta queue)
         dst.queue_write(q, src.queue_read(q))
     dst.set_counters(cnt)
 

@@ -1,0 +1,451 @@
+"""Pin 5: the HIP kernels against the REFERENCE'S OWN kernels running on the same MI355X.
+
+oracle/_ref/gfx950/ieee/*.co = /root/reference/src/wf_*.cl compiled unmodified for gfx950 and linked with AMD's own OpenCL built-in
+library (oracle/ref/Makefile, target gfx950) -- no ocl_builtins.c, no sequential driver -- loaded by ROCm's OpenCL runtime
+(oracle/ref_gpu.py).  Unlike every other reference pin of this suite there is NO builder-written stand-in between the reference's
+source and the numbers compared here.
+
+Method: LOCKSTEP, the pattern of tests/test_oracle_vs_ref.py.  Before every kernel the reference context is given the device context's
+state, queues and counters; both run the one kernel; then
+  * counters: exact;
+  * queues: the same SET of paths per queue (the reference appends with one atomic_inc per work-item, src/utils.cl:328-358, so its order
+    on a GPU is whatever the hardware schedules -- the canonical order is pinned by the x86 build, tests/test_oracle_vs_ref.py);
+  * integer columns of the state (hit index, matId, seeds, path length, flags, pixel index): exact, except hit-index flips in exact ties
+    of t, which are COUNTED against SURVEY 8(c)'s 1e-5 budget (native_recip in intersectAABB is v_rcp_f32 here, the correctly rounded
+    1/x in flx_math.h);
+  * float columns: SURVEY 8(c)'s tolerances -- rel 1e-5 / abs 1e-6 for plain arithmetic (RTOL/ATOL below, doubled as in the x86 pin),
+    rel 1e-4 downstream of atan2 / acos / native_sin / native_cos (GGX lobe), 1e-3 for GGX pdf values (ill-conditioned: common.sharp_lobe_paths);
+  * the framebuffer: counts exact, sums within the any-order bound (common.fb_close) widened by the float tolerance of the terms.
+`logic` with USE_ENV_MAP calls read_imagef and gfx950 has no image support, so env-map scenes are pinned for genRays / materials /
+traceExtension / traceShadow only (logic then runs on the device context alone); logic without the env map runs through the HIP module
+loader on the same code object if the OpenCL runtime will not take a null image handle (oracle/ref_gpu.py).
+"""
+import json
+import os
+import numpy as np
+import pytest
+import common
+from common import COL, Q
+from fluctus_amd import host, wire, driver
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL, ATOL = 2e-5, 2e-6
+FLIP_BUDGET = 1e-5
+# Moller-Trumbore's det / u / v / t are differences of products: where they cancel (grazing rays, slivers), AMD's cross / dot built-ins -- fused
+# multiply-adds -- and the plain mul + add of include/flx_math.h (what the x86 stand-in does too) legitimately differ by more than 1e-5 of the
+# result.  Such rays are COUNTED: at most OUTLIER_FRAC of the rays may exceed the tolerance, none by more than OUTLIER_CAP times.
+OUTLIER_FRAC, OUTLIER_CAP = 1e-3, 200.0        # observed (1 M rays, kitchen / conference / egyptcat): <= 2.9e-4 of the rays, <= 53 x (the normal of a near-cancelling vertex-normal blend)
+HIT_INT = [COL.HIT_I, COL.AREA_LIGHT_HIT, COL.MAT_ID, COL.PATH_LEN]
+HIT_FLT = [COL.P, COL.P + 1, COL.P + 2, COL.N, COL.N + 1, COL.N + 2, COL.UV, COL.UV + 1, COL.HIT_T]
+
+
+def hit_record_errors(sg, sr, rays):
+    """Normalised differences of the FLOAT members of the hit records of `rays` (hit index equal on both sides): |a - b| / (ATOL + RTOL * scale)
+    with the scale of the quantity the member is a component of -- t itself; max(|P|, t) for P = orig + t * dir; 1 for the unit normal;
+    max(1, |uv|) for the interpolated texture coordinate.  (A per-component relative tolerance is meaningless for a component of N or P that
+    happens to be near zero.)  Returns {member: array}."""
+    t = np.abs(sr[COL.HIT_T][rays])
+    P = np.stack([sr[COL.P + k][rays] for k in range(3)]); N = np.stack([sr[COL.N + k][rays] for k in range(3)]); uv = np.stack([sr[COL.UV + k][rays] for k in range(2)])
+    out = {}
+    with np.errstate(all="ignore"):
+        out["t"] = np.abs(sg[COL.HIT_T][rays] - sr[COL.HIT_T][rays]) / (ATOL + RTOL * t)
+        sP = np.maximum(np.abs(P).max(0), t)
+        out["P"] = np.abs(np.stack([sg[COL.P + k][rays] for k in range(3)]) - P).max(0) / (ATOL + RTOL * sP)
+        out["N"] = np.abs(np.stack([sg[COL.N + k][rays] for k in range(3)]) - N).max(0) / (ATOL + RTOL)
+        out["uv"] = np.abs(np.stack([sg[COL.UV + k][rays] for k in range(2)]) - uv).max(0) / (ATOL + RTOL * np.maximum(1.0, np.abs(uv).max(0)))
+    return out
+
+
+def edge_graze(d, so, rays, tri_idx):
+    """For rays whose closest hit differs between two correct traversals: the ray must pass through the EDGE of the triangle `tri_idx` (the nearer
+    of the two answers) -- Moller-Trumbore's u, v, 1 - u - v in float64 within 1e-4 of 0 -- or the triangle is degenerate for the ray (|det| tiny).
+    Then `u < 0` / `u + v > 1` (src/intersect.cl:76-80) is decided by the last bits of a cancelling sum, and AMD's fused cross / dot and the plain
+    mul + add legitimately disagree: one finds this triangle, the other the neighbour (a tie in t) or whatever lies behind a silhouette edge.
+    Returns a bool array: True = explained."""
+    tr = d.tris[tri_idx]
+    v0 = np.stack([tr["v0"]["p"][k] for k in "xyz"], 1).astype(np.float64)
+    v1 = np.stack([tr["v1"]["p"][k] for k in "xyz"], 1).astype(np.float64)
+    v2 = np.stack([tr["v2"]["p"][k] for k in "xyz"], 1).astype(np.float64)
+    o = np.stack([so[COL.ORIG + k][rays] for k in range(3)], 1).astype(np.float64)
+    dr = np.stack([so[COL.DIR + k][rays] for k in range(3)], 1).astype(np.float64)
+    s1, s2 = v1 - v0, v2 - v0
+    pv = np.cross(dr, s2); det = (s1 * pv).sum(1)
+    with np.errstate(all="ignore"):
+        tv = o - v0; u = (tv * pv).sum(1) / det
+        qv = np.cross(tv, s1); v = (dr * qv).sum(1) / det
+    scale = np.linalg.norm(s1, axis=1) * np.linalg.norm(s2, axis=1)
+    m = np.minimum(np.minimum(np.abs(u), np.abs(v)), np.abs(1.0 - u - v))
+    return (m < 1e-4) | (np.abs(det) < 1e-6 * scale) | ~np.isfinite(m)
+
+
+def _need_ref():
+    from oracle import ref_gpu
+    if not ref_gpu.available("ieee"):
+        pytest.skip("oracle/_ref/gfx950 not built (needs /root/reference: make -C oracle/ref gfx950 in the build container)")
+    return ref_gpu
+
+
+def _report(name, payload):
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "r05_ref_gfx950.json")
+    try:
+        j = json.load(open(path))
+    except Exception:
+        j = {}
+    j[name] = payload
+    json.dump(j, open(path, "w"), indent=1)
+
+
+_logic_backend = [None]
+
+
+def _ref_ctx(n, for_logic=False):
+    """The OpenCL runtime for everything it can run; for `logic` (image2d_t argument) fall back to the HIP module loader once the OpenCL
+    runtime has refused the null image handle."""
+    rg = _need_ref()
+    name = _logic_backend[0] if (for_logic and _logic_backend[0]) else "opencl"
+    return rg.RefGpuContext(n, backend_name=name, flavour="ieee")
+
+
+def _hip_ctx(n, ext=2, shadow=4):
+    from fluctus_amd.device import HipContext
+    g = HipContext(n)
+    g.set_option("extend_tree", ext); g.set_option("shadow_tree", shadow)
+    g.set_option("fuse", 0)                      # one reference kernel <-> one device kernel (the fused pass has its own tests vs the oracle)
+    return g
+
+
+def _sync_ref(r, g):
+    """reference context := device context (state, queues, counters, framebuffer)."""
+    common.sync(r, g)
+    r.write_pixels(0, g.read_pixels(0))
+
+
+def _cmp(g, r, d, what, kind, stats, queues_before=None):
+    """Compare after one kernel.  Returns nothing; asserts.  stats accumulates rays / flips."""
+    cg, cr = g.get_counters(), r.get_counters()
+    g.finish(); r.finish()
+    cg = np.array(cg, copy=True)
+    assert (cg == cr).all(), f"{what}: counters {cg} (device) vs {cr} (reference on gfx950)"
+    for q in range(8):
+        n = int(cg[q])
+        qa, qb = np.sort(g.queue_read(q)[:n]), np.sort(r.queue_read(q)[:n])
+        assert np.array_equal(qa, qb), f"{what}: queue {q} holds different paths ({n} entries)"
+    sg, sr = g.state_export(), r.state_export()
+    mask = np.ones(sg.shape[1], bool)
+    if kind == "extend":
+        n = int(cg[Q.EXTENSION])
+        rays = g.queue_read(Q.EXTENSION)[:n]
+        flip = sg.view(np.uint32)[COL.HIT_I][rays] != sr.view(np.uint32)[COL.HIT_I][rays]
+        stats["ext_rays"] += n; stats["flips"] += int(flip.sum())
+        if flip.any():
+            fr = rays[flip]
+            ig, ir = sg.view(np.int32)[COL.HIT_I][fr], sr.view(np.int32)[COL.HIT_I][fr]
+            tg = np.where(ig >= 0, sg[COL.HIT_T][fr], np.inf); tr_ = np.where(ir >= 0, sr[COL.HIT_T][fr], np.inf)
+            ok = edge_graze(d, sr, fr, np.where(tg <= tr_, ig, ir))
+            assert ok.all(), f"{what}: hit-index flips that are not edge grazes of the nearer triangle: rays {fr[~ok][:6]}"
+            mask[fr] = False
+    if kind == "shadow":
+        n = int(cg[Q.SHADOW])
+        rays = g.queue_read(Q.SHADOW)[:n]
+        flip = sg.view(np.uint32)[COL.SHADOW_BLOCKED][rays] != sr.view(np.uint32)[COL.SHADOW_BLOCKED][rays]
+        stats["shadow_rays"] += n; stats["shadow_flips"] += int(flip.sum())
+        mask[rays[flip]] = False
+    rtol, col_rtol = RTOL, None
+    if kind == "materials":
+        # the reference leaves pdfW uninitialised when the glossy sampler rejects (src/glossy.cl:59-60); T is 0 there
+        mask &= ~((sg[COL.T] == 0) & (sg[COL.T + 1] == 0) & (sg[COL.T + 2] == 0))
+        rtol = 1e-3
+        col_rtol = {COL.LAST_PDF_W: np.where(common.sharp_lobe_paths(d, sr), 5e-2, 1e-3)}
+    elif kind == "logic":
+        rtol = 1e-4
+    skip = ()
+    if kind == "extend":                           # the hit records' float members: normalised per quantity, outliers counted (hit_record_errors)
+        skip = tuple(HIT_FLT)
+        ok = rays[mask[rays]]
+        ok = ok[sr.view(np.int32)[COL.HIT_I][ok] >= 0]
+        for k, v in hit_record_errors(sg, sr, ok).items():
+            assert np.isfinite(v).all() and (v.size == 0 or v.max() <= OUTLIER_CAP), f"{what}: hit record {k}: max difference {v.max():.1f} x tolerance"
+            stats["hit_err_max"] = max(stats.get("hit_err_max", 0.0), float(v.max()) if v.size else 0.0)
+            stats["hit_err_above_tol"] = stats.get("hit_err_above_tol", 0) + int((v > 1).sum())
+        stats["hit_records"] = stats.get("hit_records", 0) + int(ok.size)
+        miss = rays[mask[rays]]; miss = miss[sr.view(np.int32)[COL.HIT_I][miss] < 0]
+        for c in HIT_FLT:                          # misses: EMPTY_HIT on both sides
+            assert np.array_equal(sg.view(np.uint32)[c][miss], sr.view(np.uint32)[c][miss]), f"{what}: {common.colname(c)} of missed rays"
+    fails = common.state_diff(sg, sr, rtol, 1e-5 if kind in ("materials", "logic") else ATOL, mask=mask, col_rtol=col_rtol, skip_cols=skip)
+    assert not fails, f"{what}: " + "; ".join(fails[:5])
+    if kind == "logic":
+        pg, pr = g.read_pixels(0), r.read_pixels(0)
+        assert np.array_equal(pg[:, 3], pr[:, 3]), f"{what}: framebuffer sample counts"
+        assert np.allclose(pg[:, :3], pr[:, :3], rtol=2e-4, atol=1e-5), f"{what}: framebuffer sums"
+
+
+def _lockstep(d, p, n, iters, env=None, tag=""):
+    rg = _need_ref()
+    use_env = bool(p["useEnvMap"])
+    g = _hip_ctx(n)
+    g.upload_scene(d)
+    if env is not None:
+        g.upload_envmap(env)
+    g.set_params(p)
+    driver.reset_renderer(g)
+    r = _ref_ctx(n)
+    r.upload_scene(d); r.set_params(p)
+    rl = r                                        # context that runs `logic`
+    npix = int(p["width"]) * int(p["height"])
+    stats = dict(ext_rays=0, flips=0, shadow_rays=0, shadow_flips=0, logic_backend=None, kernels=0)
+    # reset itself
+    g.wf_reset(); r.wf_reset()
+    _cmp(g, r, d, f"{tag} reset", "reset", stats)
+    for c in (g, r):
+        c.clear_queues()                          # resetRenderer: reset, then clear (src/tracer.cpp:372-382) -- the queues hold numTasks entries, no more
+    for it in range(iters):
+        steps = [("logic", lambda c: c.wf_logic(False)), ("raygen", lambda c: c.wf_raygen()), ("materials", lambda c: c.wf_materials())]
+        cnt = None
+        for name, fn in steps:
+            if name == "logic" and use_env:
+                fn(g)                             # read_imagef: not runnable on gfx950 (module docstring)
+                continue
+            tgt = rl if name == "logic" else r
+            _sync_ref(tgt, g)
+            try:
+                fn(tgt)
+            except rg.ImageArgUnsupported:
+                assert name == "logic"
+                _logic_backend[0] = "hip"
+                rl = tgt = _ref_ctx(n, for_logic=True)
+                rl.upload_scene(d); rl.set_params(p)
+                rl.pixel_index_reset(); rl.pixel_index_update(npix, r.host_pixel_idx)
+                _sync_ref(tgt, g)
+                fn(tgt)
+            fn(g)
+            stats["logic_backend"] = rl.B.name
+            _cmp(g, tgt, d, f"{tag} it{it} {name}", name, stats)
+            stats["kernels"] += 1
+        cnt = g.get_counters(); g.finish()
+        cnt = np.array(cnt, copy=True)
+        for name, fn in (("extend", lambda c: c.wf_extend()), ("shadow", lambda c: c.wf_shadow())):
+            _sync_ref(r, g)
+            fn(g); fn(r)
+            _cmp(g, r, d, f"{tag} it{it} {name}", name, stats)
+            stats["kernels"] += 1
+        for c in {id(x): x for x in (g, r, rl)}.values():
+            c.clear_queues()
+            c.pixel_index_update(npix, int(cnt[Q.RAYGEN]))
+    # resolve
+    _sync_ref(r, g)
+    g.postprocess(); r.postprocess(); g.finish(); r.finish()
+    assert np.allclose(g.read_pixels(1), r.read_pixels(1), rtol=1e-4, atol=1e-5), f"{tag}: resolved preview image"
+    _report(f"lockstep_{tag}", stats)
+    assert stats["flips"] <= max(1, int(FLIP_BUDGET * stats["ext_rays"])), stats
+    assert stats.get("hit_err_above_tol", 0) <= max(2, OUTLIER_FRAC * 4 * stats.get("hit_records", 0)), stats
+    assert stats["shadow_flips"] <= max(1, int(FLIP_BUDGET * stats["shadow_rays"])), stats
+    for c in {id(x): x for x in (r, rl)}.values():
+        c.close()
+    g.close()
+    return stats
+
+
+def test_opencl_runtime_loads_the_reference_code_objects():
+    """Every code object of oracle/_ref/gfx950/ieee loads through clCreateProgramWithBinary + clBuildProgram on the MI355X and exposes the
+    reference's kernel entry (no build from source happens on the box: /root/reference does not exist there)."""
+    rg = _need_ref()
+    B = rg.backend("opencl")
+    names = {"reset": "reset", "genRays": "genRays", "traceExtension": "traceExtension", "traceShadow": "traceShadow", "wavefrontDiffuse": "wavefrontDiffuse",
+             "wavefrontGlossy": "wavefrontGlossy", "wavefrontGGXReflection": "wavefrontGGXReflection", "wavefrontGGXRefraction": "wavefrontGGXRefraction",
+             "wavefrontDelta": "wavefrontDelta", "wavefrontAllMaterials": "wavefrontAllMaterials", "process": "process"}
+    for v in (0, 1, 4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29):
+        names[f"logic_v{v}"] = "logic"
+    for file, entry in names.items():
+        for flavour in ("ieee", "fast"):
+            prog = B.load(os.path.join(rg.co_dir(flavour), file + ".co"))
+            assert B.kernel(prog, entry)
+    _report("device", {"opencl_device": B.device_name(), "code_objects": len(names) * 2})
+
+
+@pytest.mark.parametrize("area,env,expl,impl,sep,roulette", [
+    (1, 0, 1, 1, 1, 0),
+    (1, 0, 1, 1, 0, 1),
+    (1, 0, 1, 0, 1, 0),
+    (1, 0, 0, 1, 1, 0),
+    (0, 0, 1, 1, 1, 1),
+    (1, 1, 1, 1, 1, 0),          # env map on: every kernel but logic
+    (0, 1, 1, 1, 0, 1),
+])
+def test_all_bsdfs_flag_matrix_vs_reference_on_gfx950(area, env, expl, impl, sep, roulette):
+    """All six BSDFs + textures + normal map, area-light NEE / MIS, separate vs single material queue, Russian roulette: the flag matrix of
+    tests/test_oracle_vs_ref.py, device vs the reference's kernels on the same GPU, 9 iterations in lockstep."""
+    d = common.mixed_material_scene()
+    w, h, n = 64, 48, 4096
+    p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=area, useEnvMap=env, sampleExpl=expl, sampleImpl=impl,
+                            wfSeparateQueues=sep, useRoulette=roulette, envMapStrength=1.5)
+    _lockstep(d, p, n, 9, env=host.synthetic_sky(64, 32), tag=f"mixed_a{area}e{env}x{expl}i{impl}s{sep}r{roulette}")
+
+
+def test_simple_scene_more_tasks_than_pixels_vs_reference_on_gfx950():
+    d = common.simple_scene()
+    w, h, n = 40, 30, 2048
+    p = common.scene_params(d, w, h, maxBounces=6)
+    _lockstep(d, p, n, 8, tag="simple")
+
+
+def test_egyptcat_real_asset_vs_reference_on_gfx950():
+    """A real reference asset (tests/golden/egyptcat_scene.npz: egyptcat.obj + .mtl `shader glossy` Ns 100000 + the 1024^2 texture), area light, single
+    material queue -- the reference's start-up configuration."""
+    d = common.egyptcat_scene()
+    w, h, n = 64, 48, 4096
+    p = wire.default_params(w, h, d.world_radius, d.tris.size)
+    p["wfSeparateQueues"] = 0
+    _lockstep(d, p, n, 8, tag="egyptcat")
+
+
+@pytest.mark.parametrize("tag", ["area_sep", "env_area_single_rr", "egyptcat"])
+def test_reference_on_gfx950_reproduces_the_x86_fixtures(tag):
+    """The SAME reference source through two toolchains: tests/golden/steps_*.npz were produced by the x86-64 build (oracle/_ref/libfluctus_ref.so,
+    which links the builder's ocl_builtins.c); here the gfx950 build (AMD's built-ins) starts every kernel from the fixture's input state.  What
+    differs between the two is exactly the built-in library and the NDRange driver -- this is the measurement of what the stand-in is worth:
+    integers exact (queues as sets), floats within the tolerances above."""
+    rg = _need_ref()
+    path = os.path.join(common.GOLDEN, f"steps_{tag}.npz")
+    z = np.load(path)
+    n = int(z["num_tasks"])
+    p = z["params"].view(wire.RENDER_PARAMS).reshape(())
+    d = common.fixture_scene(z)
+    use_env = bool(p["useEnvMap"])
+    names = [str(s) for s in z["names"]]
+    npix = int(p["width"]) * int(p["height"])
+    r = _ref_ctx(n)
+    r.upload_scene(d); r.set_params(p)
+    ran = {}
+    worst = {}
+    for k in range(1, len(names)):
+        name = names[k]
+        if name not in ("logic", "raygen", "materials", "extend", "shadow") or (name == "logic" and use_env):
+            continue
+        c = r
+        if name == "logic" and _logic_backend[0] == "hip":
+            c = _ref_ctx(n, for_logic=True); c.upload_scene(d); c.set_params(p)
+        fn = {"logic": lambda: c.wf_logic(False), "raygen": c.wf_raygen, "materials": c.wf_materials, "extend": c.wf_extend, "shadow": c.wf_shadow}[name]
+        for attempt in (0, 1):
+            c.pixel_index_reset(); c.pixel_index_update(npix, int(z["pixel_cursor"][k - 1]))
+            c.state_import(z["states"][k - 1])
+            for q in range(8):
+                c.queue_write(q, z["queues"][k - 1][q])
+            c.set_counters(z["counters"][k - 1])
+            try:
+                fn()
+                break
+            except rg.ImageArgUnsupported:
+                assert name == "logic" and attempt == 0
+                _logic_backend[0] = "hip"
+                c = _ref_ctx(n, for_logic=True); c.upload_scene(d); c.set_params(p)
+                fn = lambda: c.wf_logic(False)
+        cnt = c.get_counters(); c.finish()
+        assert np.array_equal(cnt, z["counters"][k]), (k, name, cnt, z["counters"][k])
+        for q in range(8):
+            m = int(z["counters"][k][q])
+            assert np.array_equal(np.sort(c.queue_read(q)[:m]), np.sort(z["queues"][k][q][:m])), (name, q)
+        sa, sb = c.state_export(), z["states"][k]
+        mask = None
+        if name == "materials":
+            mask = ~((sb[COL.T] == 0) & (sb[COL.T + 1] == 0) & (sb[COL.T + 2] == 0))
+        # (sharp lobes, egyptcat.mtl Ns 100000: D(n.h) at n.h = 1 - O(alpha^2) amplifies one ulp of cos(theta) to ~1 % -- common.sharp_lobe_paths;
+        #  x86 libm-class built-ins vs AMD's ocml: 2.7 % on one path of 4 096 observed, bound 5 %)
+        col_rtol = {COL.LAST_PDF_W: np.where(common.sharp_lobe_paths(d, sb), 5e-2, 1e-3)} if name == "materials" else None
+        fails = common.state_diff(sa, sb, 1e-3 if name == "materials" else 1e-4, 1e-5, mask=mask, col_rtol=col_rtol)
+        assert not fails, f"step {k} {name}: " + "; ".join(fails[:4])
+        ran[name] = ran.get(name, 0) + 1
+        # the largest relative difference of any float column: what AMD's built-ins vs the stand-in amount to on this input
+        with np.errstate(all="ignore"):
+            rel = np.abs(sa - sb) / np.maximum(np.abs(sb), 1e-3)
+        rel[list(common.PAD_COLS)] = 0; rel[common.INT_COLS] = 0
+        if mask is not None:
+            rel[:, ~mask] = 0
+        rel[~np.isfinite(rel)] = 0
+        worst[name] = max(worst.get(name, 0.0), float(rel.max()))
+        if c is not r:
+            c.close()
+    assert ran.get("extend") and ran.get("shadow") and ran.get("raygen") and ran.get("materials"), ran
+    _report(f"x86_fixture_{tag}", {"kernels_run": ran, "max_rel_diff_gfx950_builtins_vs_x86_standin": worst})
+    r.close()
+
+
+def _steady_state(workload, n, iters):
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    from fluctus_amd.device import HipContext
+    g = HipContext(n)                          # the shipped defaults (4-wide trees, persistent closest hit, fused pass)
+    g.upload_scene(d)
+    if p["useEnvMap"]:
+        g.upload_envmap(env)
+    g.set_params(p)
+    driver.reset_renderer(g)
+    npix = int(p["width"]) * int(p["height"])
+    for _ in range(iters):
+        driver.benchmark_iteration(g, npix)
+    g.wf_logic(False); g.wf_raygen(); g.wf_materials()
+    cnt = g.get_counters(); g.finish()
+    return d, p, g, np.array(cnt, copy=True)
+
+
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "egyptcat"])
+def test_traversal_1M_rays_vs_reference_on_gfx950(workload):
+    """2^20 paths in the steady state of BASELINE's configurations (kitchen-proc 1080p / 8 bounces, conference-proc, the egyptcat asset at the
+    reference's benchmark settings): the extension and shadow queues of one iteration traced by the reference's traceExtension / traceShadow
+    (src/wf_extrays.cl:5-36, src/wf_shadowrays.cl:6-38, gfx950 code objects under ROCm's OpenCL) and by the shipped default HIP kernels from the
+    same state.  Hit records: integers exact, floats at RTOL / ATOL; hit-index flips (ties) and shadow flips counted against 1e-5.  The
+    reference kernels' own time on this GPU is recorded beside the HIP kernels' (r05_ref_gfx950.json): same GPU, same rays, same tree."""
+    rg = _need_ref()
+    n = 1 << 20
+    d, p, g, cnt = _steady_state(workload, n, 2 * int(__import__("bench").WORKLOADS[workload][6]) + 2)
+    out = {"paths": n, "ext_rays": int(cnt[Q.EXTENSION]), "shadow_rays": int(cnt[Q.SHADOW])}
+    for flavour in ("ieee", "fast"):
+        r = rg.RefGpuContext(n, backend_name="opencl", flavour=flavour)
+        r.upload_scene(d); r.set_params(p)
+        common.sync(r, g)
+        s0 = s_in = r.state_export()
+        r.timed = True
+        for rep in range(3):                     # timing: best of 3 from the same input
+            r.state_import(s0)
+            r.wf_extend(); r.wf_shadow(); r.finish()
+            out[f"ref_{flavour}_traceExtension_ms"] = min(out.get(f"ref_{flavour}_traceExtension_ms", 1e9), r.last_ms["traceExtension"])
+            out[f"ref_{flavour}_traceShadow_ms"] = min(out.get(f"ref_{flavour}_traceShadow_ms", 1e9), r.last_ms["traceShadow"])
+        if flavour == "ieee":
+            sr = r.state_export()
+        r.close()
+    g.profile_enable(1); g.profile_reset()
+    g.wf_extend(); g.wf_shadow(); g.finish()
+    prof = g.profile_get(); g.profile_enable(0)
+    out["hip_profile_ms"] = {k: (v[0] / max(1, v[1])) for k, v in prof.items() if v[1]}
+    sg = g.state_export()
+    ne, ns = int(cnt[Q.EXTENSION]), int(cnt[Q.SHADOW])
+    er, sh = g.queue_read(Q.EXTENSION)[:ne], g.queue_read(Q.SHADOW)[:ns]
+    ig, ir = sg.view(np.uint32), sr.view(np.uint32)
+    flip = ig[COL.HIT_I][er] != ir[COL.HIT_I][er]
+    same = er[~flip]
+    for c in HIT_INT:
+        assert np.array_equal(ig[c][same], ir[c][same]), f"{workload}: {common.colname(c)} differs on rays whose hit index agrees"
+    hit = same[ig[COL.HIT_I][same].view(np.int32) >= 0]
+    errs = hit_record_errors(sg, sr, hit)
+    out["hit_record_float_errors_in_units_of_tolerance"] = {k: {"max": float(v.max()) if v.size else 0.0, "frac_above_1": float((v > 1).mean()) if v.size else 0.0,
+                                                               "frac_above_4": float((v > 4).mean()) if v.size else 0.0} for k, v in errs.items()}
+    _report(f"traversal_1M_{workload}", out)
+    for k, v in errs.items():
+        assert np.isfinite(v).all(), f"{workload}: {k}: non-finite difference"
+        assert v.max() <= OUTLIER_CAP and (v > 1).mean() <= OUTLIER_FRAC, f"{workload}: {k}: {out['hit_record_float_errors_in_units_of_tolerance'][k]}"
+    if flip.any():                                 # every flip must be an edge graze of the nearer triangle (edge_graze): a tie or a silhouette
+        fr = er[flip]
+        hg, hr = ig[COL.HIT_I][fr].view(np.int32), ir[COL.HIT_I][fr].view(np.int32)
+        tg = np.where(hg >= 0, sg[COL.HIT_T][fr], np.inf); tr_ = np.where(hr >= 0, sr[COL.HIT_T][fr], np.inf)
+        nearer = np.where(tg <= tr_, hg, hr)
+        ok = edge_graze(d, s_in, fr, nearer)
+        out["flips_explained_as_edge_grazes"] = int(ok.sum())
+        _report(f"traversal_1M_{workload}", dict(out, hit_index_flips=int(flip.sum())))
+        assert ok.all(), f"{workload}: {int((~ok).sum())} of {fr.size} hit-index flips are not edge grazes of the nearer triangle: rays {fr[~ok][:6]}"
+    sflip = ig[COL.SHADOW_BLOCKED][sh] != ir[COL.SHADOW_BLOCKED][sh]
+    out.update(hit_index_flips=int(flip.sum()), shadow_flips=int(sflip.sum()))
+    _report(f"traversal_1M_{workload}", out)
+    assert flip.sum() <= max(1, FLIP_BUDGET * ne) and sflip.sum() <= max(1, FLIP_BUDGET * ns), out
+    g.close()
