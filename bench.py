@@ -121,7 +121,7 @@ def capture_key(args, ctx, p, C=1):
     from fluctus_amd import build
     return {"workload": args.workload, "width": int(p["width"]), "height": int(p["height"]), "max_bounces": int(p["maxBounces"]),
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
-            "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
+            "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
             "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"),
             "source_hash": build.source_hash()}
 
@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
     ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
+    ap.add_argument("--shadow-split", type=int, default=-1, help="tail splitting of the any-hit kernel: node-visit budget of the pass over the queue | budget of a second pass << 8; 0 = off, -1 = library default")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
@@ -240,6 +241,8 @@ def main():
             c_.set_option("refill_extend", args.refill_extend)
         if args.refill_shadow >= 0:
             c_.set_option("refill_shadow", args.refill_shadow)
+        if args.shadow_split >= 0:
+            c_.set_option("shadow_split", args.shadow_split)
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene
@@ -554,7 +557,7 @@ def main():
                                    ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
                        "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
-                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "overlap": ctx.get_option("overlap"),
+                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},

@@ -19,6 +19,8 @@ void launch_extend(hipStream_t, const State &, const Queues &, const Scene &, co
 void launch_shadow(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *, int);
 void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
+void launch_shadow4_split(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *, uint32_t, uint4 *, uint32_t, uint4 *, uint32_t, int, int, uint32_t);
+uint32_t shadow_split_lists(); uint32_t shadow_split_count_words();
 void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int);
@@ -58,6 +60,12 @@ struct flx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;              // the shadow kernel runs here, concurrently with the extension kernel
     hipEvent_t evPreExt = nullptr, evShadow = nullptr, evPostLogic = nullptr;
+#ifdef FLX_LAB_NOJOIN
+    // lab build only (-DFLX_LAB_NOJOIN; RESULTS INVALID, timing only): the ceiling of taking the any-hit kernel's tail off the step's critical
+    // path -- the main stream does not join the shadow stream after flx_wf_shadow; the next-but-one `logic` waits for it instead (the throttle a
+    // deferred NEE-consume kernel would impose).  The kernel reads a snapshot of the queue counters (the live ones are cleared under it).
+    hipEvent_t evLab[2] = {nullptr, nullptr}; uint32_t labIter = 0; uint32_t *labCounters = nullptr;
+#endif
     int phase = 0;                              // the call-sequence state machine (enum Phase below): ONE explicit state instead of deferral / chain booleans
     int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
     int overlapOpt = -1;                        // option "overlap": -1 = the default (pickSchedule), else as set
@@ -98,6 +106,12 @@ struct flx_ctx {
     // (closest hit: on by default -- refillMin 16, waitMax 32: kitchen 0.82 -> 0.61 ms per 4 M rays; any hit: off by default, pickSchedule)
     int refillExt = 16 | (32 << 8), refillShadow = 0;
     int refillShadowOpt = -1;                   // option "refill_shadow": -1 = the default (off), else as set
+    // tail splitting of the thread-per-ray any-hit kernel (trace4.hip: k_shadow4s): budget of the pass over the queue | budget of a second pass << 8
+    // (0 = the second pass finishes every ray); 0 = off (k_shadow4).  Continuation records: 64 B each, in sub-lists of splitCapA / splitCapB slots (numTasks / 2 and / 8 in all).
+    int shadowSplit = 0;
+    uint32_t splitParity = 0;                   // counter set of the next split launch (trace4.hip: launch_shadow4_split)
+    uint32_t splitLimit = 0;                    // test hook (option shadow_split_limit): use only this many slots per sub-list (0 = all), to reach the full-list path
+    uint32_t *splitCounts = nullptr; uint4 *splitRecA = nullptr, *splitRecB = nullptr; uint32_t splitCapA = 0, splitCapB = 0;
     // The persistent-wave extension kernel leaves RAW hit records (flx_trace.h): true from flx_wf_extend until they are committed -- by the
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as an entry point that could observe a hit record runs (transition(): commitRaw).
@@ -309,6 +323,12 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
 #ifdef FLX_LAB_RSTATS
     flxd::g_lab_rstats = c->stats;
 #endif
+    // per sub-list: numTasks / 2 (first pass) and / 8 (second pass) records over all lists, whole waves
+    c->splitCapA = ((num_tasks / 2 / shadow_split_lists()) + 64u) & ~63u; c->splitCapB = ((num_tasks / 8 / shadow_split_lists()) + 64u) & ~63u;
+    if (dalloc(c, c->fixedAllocs, &c->splitCounts, shadow_split_count_words()) || dalloc(c, c->fixedAllocs, &c->splitRecA, (size_t)c->splitCapA * shadow_split_lists() * 4) ||
+        dalloc(c, c->fixedAllocs, &c->splitRecB, (size_t)c->splitCapB * shadow_split_lists() * 4))
+        return fail("hipMalloc(continuation records)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->splitCounts, 0, (size_t)shadow_split_count_words() * 4, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
@@ -658,6 +678,9 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     if (!raw && materialise(c)) return 1;
     c->rawHits = false;
     flushExt(c);                                       // logic's scan overwrites the source-queue counters
+#ifdef FLX_LAB_NOJOIN
+    if (c->labIter >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evLab[c->labIter & 1u], 0));      // the shadow kernel BEFORE the last one
+#endif
     { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, extOrderFor(c, fused, raygenFirst), raw); }
     LAUNCHED(c);
     c->matQueuesEmpty = false;
@@ -743,10 +766,27 @@ int flx_wf_shadow(flx_ctx *c)
             launch_shadow4r(s, c->st, c->qs, c->sc, c->params, spill, (uint32_t)c->numCUs, c->refillShadow, cur);
             c->cursorDirty[1] = true;
         }
+#ifdef FLX_LAB_NOJOIN
+        else if (c->shadowTree == 4 && c->wideOK && overlapped) {
+            if (!c->labCounters) HIPCHK(c, hipMalloc(&c->labCounters, 2 * 32));
+            Queues q2 = c->qs; q2.counters = c->labCounters + 8 * (c->labIter & 1u);
+            HIPCHK(c, hipMemcpyAsync(q2.counters, c->qs.counters, 32, hipMemcpyDeviceToDevice, s));
+            launch_shadow4(s, c->st, q2, c->sc, c->params, spill, nullptr);
+        }
+#endif
+        else if (c->shadowTree == 4 && c->wideOK && c->shadowSplit > 0 && !c->statsOn)
+            launch_shadow4_split(s, c->st, c->qs, c->sc, c->params, spill, c->splitCounts, c->splitParity++, c->splitRecA, c->splitCapA, c->splitRecB, c->splitCapB, c->shadowSplit & 0xFF, c->shadowSplit >> 8, c->splitLimit);
         else if (c->shadowTree == 4 && c->wideOK) launch_shadow4(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr);
         else launch_shadow(s, c->st, c->qs, c->sc, c->params, spill, c->statsOn ? c->stats : nullptr, c->xcdRemap);
     }
     LAUNCHED(c);
+#ifdef FLX_LAB_NOJOIN
+    if (overlapped) {
+        if (!c->evLab[0]) { HIPCHK(c, hipEventCreateWithFlags(&c->evLab[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->evLab[1], hipEventDisableTiming)); }
+        HIPCHK(c, hipEventRecord(c->evLab[c->labIter & 1u], s)); c->labIter++;
+        return 0;
+    }
+#endif
     if (overlapped) { HIPCHK(c, hipEventRecord(c->evShadow, s)); HIPCHK(c, hipStreamWaitEvent(c->stream, c->evShadow, 0)); }
     if ((c->profile == 1 || c->profile == 2) && overlapped && c->spanStart) {
         // span of the two traversals: from the earlier start (the shadow kernel's when it ran ahead) to the join
@@ -1298,6 +1338,8 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "refill_extend") == 0 && refill_value_ok(value)) { ENTER(c, CALL_OBSERVE); c->refillExt = value; return 0; }
     if (name && strcmp(name, "refill_shadow") == 0 && (value == -1 || refill_value_ok(value))) { ENTER(c, CALL_OBSERVE); c->refillShadowOpt = value; pickSchedule(c); return 0; }
     if (name && (strcmp(name, "refill_extend") == 0 || strcmp(name, "refill_shadow") == 0)) { c->err = "flx_set_option: refill value must be 0 or refillMin (1..64) | waitMax (0..64) << 8"; return 1; }
+    if (name && strcmp(name, "shadow_split") == 0 && value >= 0 && (value & 0xFF) <= 255 && (value >> 8) <= 255 && ((value & 0xFF) > 0 || value == 0)) { ENTER(c, CALL_OBSERVE); c->shadowSplit = value; return 0; }
+    if (name && strcmp(name, "shadow_split_limit") == 0 && value >= 0) { ENTER(c, CALL_OBSERVE); c->splitLimit = (uint32_t)value; return 0; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
     c->err = std::string("flx_set_option: unknown option ") + (name ? name : "(null)");
@@ -1314,7 +1356,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;

@@ -221,4 +221,32 @@ __device__ __forceinline__ bool traverse4(const Scene &sc, WStack &stk, f3 orig,
 #undef FLX_WAVE_TICK
 }
 
+// ---- any-hit traversal with a node-visit BUDGET, resumable (trace4.hip: k_shadow4s, "tail splitting").
+// A thread-per-ray wave lives as long as its longest ray: on the kitchen's shadow rays (6.8 wide-node visits in the mean, p95 12, max 58) a wave of
+// k_shadow4 runs 18 rounds with 20 of its 64 lanes busy.  Here a ray that has used up its budget in front of an INNER node SUSPENDS: it leaves the loop
+// with the node it stood on pushed on top of its stack; the kernel writes {queue index, sp, stack} to a continuation record and a later launch -- its rays
+// compacted, a new budget -- goes on from there.  The ray's own sequence of node and leaf visits is exactly k_shadow4's (same order, same arithmetic, the
+// any-hit t bound never shrinks), only cut across launches, so shadowRayBlocked is bit-identical by construction.
+// Returns 0 not occluded | 1 occluded | 2 suspended (sp entries on the stack, the next node on top).  maxKeep = entries a continuation record holds;
+// a ray whose stack is deeper (or partly paged out) simply keeps going.
+#define FLX_SPLIT_KEEP 14
+template <int ANY_ORDER>
+__device__ __forceinline__ int traverse4_any_budget(const Scene &sc, WStack &stk, const WRay &r, float tmax, int &sp, uint32_t cur, int budget)
+{
+    const float4 *wn = reinterpret_cast<const float4 *>(sc.wnodes);
+    float u, v; int tri; uint32_t nTri = 0;
+    for (;;) {
+        while (!(cur & FLX_WIDE_LEAF_BIT) && budget > 0) { wide_node_visit<true, ANY_ORDER>(wn, stk, r, tmax, sp, cur); budget--; }
+        if (!(cur & FLX_WIDE_LEAF_BIT)) {                         // out of budget in front of an inner node
+            if (stk.base == 0 && sp < FLX_SPLIT_KEEP) { stk.slot(sp) = cur; sp++; return 2; }
+            budget = 0x7fffffff;                                  // too deep for a record: finish here
+            continue;
+        }
+        if (cur == FLX_RAY_DONE) return 0;
+        if (wide_leaf_visit<true, false>(sc.wleaf, r, cur, tmax, u, v, tri, nTri, nullptr)) return 1;
+        cur = stk.pop(sp);
+        if (cur == FLX_RAY_DONE) return 0;
+    }
+}
+
 } // namespace flxd

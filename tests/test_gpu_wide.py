@@ -611,3 +611,64 @@ def test_persistent_kernels_with_empty_and_tiny_queues():
             c.wf_extend(); c.wf_shadow(); c.clear_queues(); c.pixel_index_update(w * h, int(cnt[Q.RAYGEN]))
     assert not common.state_diff(g.state_export(), o.state_export(), 0.0, 0.0)
     g.close()
+
+
+@pytest.mark.parametrize("split", [1, 2 | (1 << 8), 8, 8 | (8 << 8), 3 | (200 << 8)])
+def test_shadow_tail_split_is_bit_identical_small(split):
+    """Tail splitting of the any-hit query (trace4.hip: k_shadow4s; option shadow_split = budget of the pass over the queue | budget of a second pass << 8):
+    a ray that has spent its node-visit budget suspends into a 64-byte continuation record and a later launch resumes it.  The ray's own visit sequence is
+    k_shadow4's, so shadowRayBlocked must be IDENTICAL -- here with budgets of 1-3 visits, where nearly every ray suspends (twice), on the all-BSDF scene with
+    both light types (area light: last-hit-slot-first order; environment only: far -> near order), with an odd path count (a partial last wave), and with
+    the record sub-lists cut to 5 slots (option shadow_split_limit), so that they OVERFLOW and the rays without a record finish inside their wave."""
+    from fluctus_amd.device import HipContext
+    d = common.mixed_material_scene()
+    w, h = 64, 48
+    for area, envm, n, limit in ((1, 1, 4096 + 37, 0), (0, 1, 4096 + 37, 0), (1, 0, 4096 + 37, 5), (0, 1, 192, 1)):
+        p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=area, useEnvMap=envm, wfSeparateQueues=1)
+        ctx = []
+        for s in (0, split):
+            g = HipContext(n)
+            g.upload_scene(d); g.upload_envmap(host.synthetic_sky(64, 32)); g.set_params(p)
+            g.set_option("shadow_split", s); g.set_option("shadow_split_limit", limit)
+            driver.reset_renderer(g)
+            ctx.append(g)
+        a, b = ctx
+        assert a.get_option("shadow_split") == 0 and b.get_option("shadow_split") == split
+        rays = 0
+        for it in range(10):
+            ca, cb = driver.benchmark_iteration(a, w * h), driver.benchmark_iteration(b, w * h)
+            assert (ca == cb).all(), f"it{it}: {ca} vs {cb}"
+            rays += int(ca[Q.SHADOW])
+            sa, sb = a.state_export(), b.state_export()
+            assert np.array_equal(sa.view(np.uint32)[COL.SHADOW_BLOCKED], sb.view(np.uint32)[COL.SHADOW_BLOCKED]), f"area {area} env {envm} n {n} it{it}: shadowRayBlocked"
+            fails = common.state_diff(sa, sb, 0.0, 0.0)
+            assert not fails, "; ".join(fails[:4])
+        assert rays > 2 * n
+        for g in ctx:
+            g.close()
+
+
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "courtyard-1440p"])
+def test_shadow_tail_split_is_bit_identical_full_size(workload):
+    """The same at BASELINE's sizes, 1 M paths, the budgets the bench uses and a three-pass setting: 12 free-running iterations of the shipped default
+    path with and without the split, counters every iteration, the whole state at the end."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    ref = None
+    for s in (0, 8, 8 | (8 << 8)):
+        g = HipContext(n)
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p)
+        g.set_option("shadow_split", s)
+        driver.reset_renderer(g)
+        cnts = [driver.benchmark_iteration(g, npix) for _ in range(12)]
+        st, px = g.state_export(), g.read_pixels(0)
+        if ref is None:
+            ref = (cnts, st, px)
+        else:
+            assert all((x == y).all() for x, y in zip(cnts, ref[0])), f"{workload} split {s}: counters"
+            fails = common.state_diff(st, ref[1], 0.0, 0.0)
+            assert not fails, f"{workload} split {s}: " + "; ".join(fails[:4])
+            assert common.fb_close(px, ref[2])
+        g.close()
