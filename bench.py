@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): the kitchen-class scene at 1920x1080, 8 bounces, env-map MIS, separate
 material queues.  Country-Kitchen.obj is a missing blob in the reference checkout, so the scene is the
 deterministic procedural stand-in "kitchen-proc" (~0.5 M triangles, the real .mtl's material-type mix,
-SURVEY 8(d)) with a synthetic HDR sky; SBVH built by the host library.  NUM_TASKS = 8 388 608 paths in flight per
+SURVEY 8(d)) under the reference's own environment map (assets/env_maps/night.hdr, tests/golden/night_env.npz); SBVH built by the host library.  NUM_TASKS = 8 388 608 paths in flight per
 GPU (the reference's `wfBufferSize` setting, re-tuned for this chip -- see the comment at NUM_TASKS).
 
 A step = one benchmark-style iteration of the reference's runBenchmark body (src/tracer.cpp:433-439):
@@ -96,8 +96,26 @@ def build_workload(width=None, height=None, name="kitchen"):
     p = wire.default_params(width, height, d.world_radius, d.tris.size)
     wire.look_at(p, cam, target, fov=60.0)
     p["maxBounces"], p["useEnvMap"], p["useAreaLight"], p["wfSeparateQueues"] = bounces, use_env, use_area, (0 if name in SINGLE_MATERIAL_QUEUE else 1)
-    env = host.synthetic_sky(512, 256)
+    env = night_env()
     return d, p, env
+
+
+_night = []
+
+
+def night_env():
+    """The reference's own environment map, assets/env_maps/night.hdr 512 x 256 (the map of the kitchen and courtyard configurations),
+    from tests/golden/night_env.npz (scripts/make_envmap_fixture.py: pixels as read by the reference's rgbe.cpp); the alias / pdf tables are built by
+    host/envmap.cpp.  Rounds 1-4 measured with host.synthetic_sky instead; a real night sky is far peakier (it changes the shadow-ray mix)."""
+    if not _night:
+        import hashlib
+        from fluctus_amd import host
+        z = np.load(os.path.join(ROOT, "tests", "golden", "night_env.npz"))
+        e = host.envmap_from_rgb(int(z["w"]), int(z["h"]), z["rgb"])
+        got = hashlib.sha256(e.prob.tobytes() + e.alias.tobytes() + e.pdf.tobytes()).hexdigest()
+        assert got == str(z["tables_sha256"]), "night_env.npz: the sampling tables built here differ from the ones the fixture was made with"
+        _night.append(e)
+    return _night[0]
 
 
 def step_async(ctx):
@@ -123,6 +141,9 @@ def capture_key(args, ctx, p, C=1):
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
             "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"),
+            "shadow_split": ctx.get_option("shadow_split"),
+            # which BINARY ran: the shipped library or an A/B variant (FLX_HIP_LIB, e.g. a -DFLX_LAB build of the same sources), and its compile flags
+            "library": os.path.basename(os.environ.get("FLX_HIP_LIB") or "libfluctus_hip.so"), "build_flags": " ".join(build.HIP_FLAGS),
             "source_hash": build.source_hash()}
 
 
@@ -198,7 +219,7 @@ def main():
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
-    ap.add_argument("--kernel-timing", type=int, default=3, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel (roofline) only")
+    ap.add_argument("--kernel-timing", type=int, default=4, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel only, 4 the three kernels of the roofline block (extension, logic, shadow)")
     args = ap.parse_args()
 
     import torch
@@ -411,6 +432,7 @@ def main():
     # any difference makes it stale and the line says which keys differ instead of quoting it.
     traffic = traffic_lines = traffic_lanes = traffic_valu = None
     traffic_stale = None
+    passes = {}
     key = capture_key(args, ctx, p, C)
     tpath = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(tpath):
@@ -423,6 +445,7 @@ def main():
                 traffic_lines = tj.get("extend_read_requests_128B")
                 traffic_lanes = tj.get("extend_lanes_per_valu_instruction")
                 traffic_valu = tj.get("extend_valu_instructions")
+                passes = tj.get("passes") or {}
             else:
                 traffic_stale = diff
         except Exception as e:
@@ -512,8 +535,47 @@ def main():
         ach, src = traffic / launch_s / 1e9, "counters"
     else:
         ach, src = None, None
+    # ---- the instruction-issue roof.  A wave64 VALU instruction occupies its SIMD's 16-lane ALU for 4 cycles (scripts/ubench/valu_pairs*.hip measured
+    # 4.0-4.3 SIMD-cycles per dependent-free instruction, single-pipe ops included), so a kernel cannot retire more than SIMDs x clock / 4 wave-instructions
+    # per second whatever its lanes do: issue_frac = instructions x 4 / (SIMDs x clock x launch time).  The traversal kernels sit near 0.8 of THAT roof
+    # at half their lanes idle -- HBM (frac, above) is not what bounds them on a cache-resident tree -- while the logic pass is the one HBM-bound kernel.
+    prop = torch.cuda.get_device_properties(local_rank)
+    simds = int(prop.multi_processor_count) * 4
+    clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+    CYC = 4.0
+
+    def valu_block(insts, lanes, secs):
+        if not insts or not secs:
+            return None
+        return {"instructions_per_launch": insts, "cycles_per_instruction": CYC, "simds": simds, "clock_GHz": clock_hz / 1e9,
+                "issue_frac": insts * CYC / (simds * clock_hz * secs), "lanes_per_instruction": lanes, "useful_lane_frac": (lanes / 64.0) if lanes else None}
+
+    def pass_block(name, prof_keys, label):
+        pb = passes.get(name) or {}
+        ms, n = 0.0, 0
+        for k_ in prof_keys:
+            if prof.get(k_, (0.0, 0))[1]:
+                ms, n = prof[k_]; break
+        secs = (ms / n * 1e-3) if n else None
+        by = pb.get("hbm_bytes_per_launch")
+        hb = (by / secs / 1e9) if (by and secs) else None
+        vb = valu_block(pb.get("valu_instructions_per_launch"), pb.get("lanes_per_valu_instruction"), secs)
+        fr = {"hbm": (hb / HBM_PEAK_GBS) if hb else None, "valu": vb["issue_frac"] if vb else None}
+        best = max((v, k_) for k_, v in fr.items() if v is not None)[1] if any(v is not None for v in fr.values()) else None
+        return {"kernel": label, "launch_ms": (secs * 1e3) if secs else None, "timed": ("timed region" if prof_keys[0] not in untimed else "extra untimed pass"),
+                "bound": best, "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["hbm"], "traffic": by}, "valu": vb}
+    other = {"logic": pass_block("logic", ["logic_fused", "logic"], "logic (+ the inlined material step) + queue scan + scatter: k_logic<FUSE, RAW>, k_queue_scan, k_queue_scatter"),
+             "shadow": pass_block("shadow", ["shadow"], "traceShadow (k_shadow4: 4-wide quantised tree, thread per ray)" if not ctx.get_option("shadow_split") else "traceShadow (k_shadow4s: tail-split)")}
+    ext_valu = valu_block(traffic_valu, traffic_lanes, launch_s if launch_s > 0 else None)
+    ext_hbm_frac = (ach / HBM_PEAK_GBS) if ach is not None else None
+    ext_bound = "hbm"
+    if ext_valu and (ext_hbm_frac is None or ext_valu["issue_frac"] > ext_hbm_frac):
+        ext_bound = "valu-issue"
     roofline = {"kernel": ("traceExtension (k_extend4: 4-wide quantised tree)" if not ctx.get_option("refill_extend") else "traceExtension (k_trace4r: 4-wide quantised tree, persistent waves with lane refill)") if args.extend_tree == 4 else "traceExtension (k_extend: binary tree)",
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach is not None else None, "traffic": traffic,
+                # `bound`: whichever roof the kernel sits closer to -- "hbm" (achieved / peak / frac below, the contract's fields) or "valu-issue"
+                # (roofline.valu: wave-instruction issue, the roof a divergent traversal on a cache-resident tree actually hits; MFMA has no work on this path)
+                "bound": ext_bound, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_hbm_frac, "traffic": traffic,
+                "valu": ext_valu, "other_kernels": other,
                 "frac_source": src, "traffic_capture_stale_keys": traffic_stale, "capture_key": key,
                 "definition": "achieved = fabric-side bytes (memory-side L2 requests; Infinity-Cache hits included = upper bound of HBM proper) of the extension kernel per launch (profiles/traffic_<workload>.json: rocprofv3 --pmc request counters by size, separate passes, captured on THIS configuration and THESE kernel sources: capture_key) / the kernel's average launch time measured live with HIP events on its stream inside the timed region.  null when no capture matches (traffic_capture_stale_keys says why); frac_own = bytes the running kernel itself touches per ray, an upper bound.  launch_ms: as it runs in the timed region beside the concurrent shadow traversal; launch_ms_alone / frac_alone: same kernel, same steady state, serial schedule (untimed extra pass).",
                 "frac_alone": (ach * launch_s / alone_s / HBM_PEAK_GBS) if (ach is not None and alone_s > 0 and launch_s > 0) else None,
@@ -551,8 +613,9 @@ def main():
             "windows": {"count": nwin, "headline": "median window", "Mrays_s": [float(x) for x in win_mrays], "ms_per_step": [float(e / args.steps * 1e3) for e in wins[:, 0]],
                         "spread_pct": float((win_mrays.max() - win_mrays.min()) / win_mrays[med] * 100.0)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS, "
+            "dtype": "f32", "data": ("real (reference asset egyptcat.obj + .mtl + texture)" if args.workload == "egyptcat" else
+                                     "synthetic (procedural scene, deterministic); environment map: the reference's assets/env_maps/night.hdr" if int(p["useEnvMap"]) else "synthetic (procedural scene, deterministic)"),
+            "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS under night.hdr, "
                                     "separate material queues") if args.workload == "kitchen" else
                                    ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),

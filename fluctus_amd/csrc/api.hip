@@ -79,6 +79,7 @@ struct flx_ctx {
     int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 31 all six; chosen at flx_upload_scene
     int pendFirst = 0;                          // the deferred flx_wf_logic's `first` (phases PH_DEFER_*)
     bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
+    bool raygenQueueEmpty = false;              // ... and the raygen counter (ext_order 2 ranks the regenerated paths from zero: extOrderFor)
     uint32_t numTasks = 0;
     std::string err;
     State st {};
@@ -138,7 +139,7 @@ struct flx_ctx {
     uint32_t *pinnedIdx = nullptr; int nextIdxSlot = 0;
     std::vector<PendingCounters> pending;
     // profiling
-    int profile = 0;              // 0 off | 1 time every kernel | 2 the traversal kernels + span | 3 the extension kernel only
+    int profile = 0;              // 0 off | 1 time every kernel | 2 the traversal kernels + span | 3 the extension kernel only | 4 extension + logic + shadow
     hipEvent_t spanStart = nullptr;             // pending FLX_K_TRACE_SPAN start (recorded in flx_wf_extend)
     std::vector<PendingEvent> events;
     std::vector<hipEvent_t> eventPool;
@@ -166,11 +167,12 @@ static hipEvent_t getEvent(flx_ctx *c)
 struct ScopedTimer {
     flx_ctx *c; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     bool on;
-    // profile level 1 = every kernel, 2 = the two traversal kernels + their span, 3 = the extension kernel only
-    // (each event pair costs a few us of stream time)
+    // profile level 1 = every kernel, 2 = the two traversal kernels + their span, 3 = the extension kernel only, 4 = the three kernels the bench line
+    // prices against a roof: extension, (fused) logic, shadow  (each event pair costs a few us of stream time)
     ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream)
     {
-        on = c->profile == 1 || (c->profile == 2 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW)) || (c->profile == 3 && k == FLX_K_EXTEND);
+        on = c->profile == 1 || (c->profile == 2 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW)) || (c->profile == 3 && k == FLX_K_EXTEND) ||
+             (c->profile == 4 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW || k == FLX_K_LOGIC || k == FLX_K_LOGIC_FUSED));
         if (on) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); }
     }
     ~ScopedTimer() { if (on) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
@@ -640,7 +642,7 @@ uint32_t flx_local_pixels(flx_ctx *c) { return c->fr.localPixels; }
 #define READY(c, call) do { ENTER(c, call); NEED(c, (c)->haveParams, "set params first (flx_set_params)"); NEED(c, (c)->sc.bnodes, "upload a scene first (flx_upload_scene)"); HIPCHK(c, hipSetDevice((c)->device)); } while (0)
 #define LAUNCHED(c) HIPCHK(c, hipGetLastError())
 
-int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
+int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); c->raygenQueueEmpty = false; /* k_reset fills the raygen queue */ { ScopedTimer t(c, FLX_K_RESET); launch_reset(c->stream, c->st, c->qs, c->fr, c->params); } LAUNCHED(c); return 0; }
 // Appending a source queue a second time before the pending lengths were folded into the counter would compute slots from
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
@@ -667,7 +669,9 @@ static int materialise(flx_ctx *c)
 // how this fused pass lists the traced paths in the extension queue: ext_order 2 (regenerated + continuing paths merged by path id) needs
 // genRays to follow in the same chain -- the scatter writes the regenerated paths' entries, genRays then must not -- and falls back to 1
 // (continuing paths by id, genRays appends its own block whenever it is called) otherwise
-static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && !raygenFirst) ? 1 : c->extOrder; }
+// ... and a raygen queue that was EMPTY before this logic pass: the merged list is ranked from the scan offsets, which start at the raygen counter's old
+// value, while genRays with appendExt 0 would never fill the slots in front (flx_wf_reset leaves numTasks entries there without a clear: round 4's advisor)
+static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) ? 1 : c->extOrder; }
 static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
     // RAW hit records are committed by the fused pass itself when genRays follows in the same chain (logic.hip: k_logic<FUSE, RAW>); the plain
@@ -683,7 +687,7 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 #endif
     { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, extOrderFor(c, fused, raygenFirst), raw); }
     LAUNCHED(c);
-    c->matQueuesEmpty = false;
+    c->matQueuesEmpty = false; c->raygenQueueEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
     return 0;
 }
@@ -866,7 +870,7 @@ int flx_mk_stats_reset(flx_ctx *c) { ENTER(c, CALL_OBSERVE); HIPCHK(c, hipSetDev
 int flx_clear_queues(flx_ctx *c)
 {
     ENTER(c, CALL_NEUTRAL);
-    c->qs.extPend = 0; c->matQueuesEmpty = true;
+    c->qs.extPend = 0; c->matQueuesEmpty = true; c->raygenQueueEmpty = true;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
     if (c->cursorDirty[0] || c->cursorDirty[1]) {       // the block cursors of the persistent traversal kernels go with the counters
@@ -933,7 +937,7 @@ int flx_end_iteration_async(flx_ctx *c)
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend, c->qs.cursors);
     c->cursorDirty[0] = c->cursorDirty[1] = false;      // (k_end_iteration zeroes the block cursors with the counters)
     c->qs.extPend = 0;
-    c->matQueuesEmpty = true;                           // it clears the queue counters
+    c->matQueuesEmpty = true; c->raygenQueueEmpty = true;      // it clears the queue counters
     LAUNCHED(c);
     return 0;
 }
@@ -1219,7 +1223,7 @@ int flx_gather_local(flx_ctx **ctxs, uint32_t n, uint32_t root, float *out_host)
 }
 
 // ---- measurement
-int flx_profile_enable(flx_ctx *c, int on) { ENTER(c, CALL_QUIET); c->profile = on < 0 ? 0 : on > 3 ? 1 : on; return 0; }
+int flx_profile_enable(flx_ctx *c, int on) { ENTER(c, CALL_QUIET); c->profile = on < 0 ? 0 : on > 4 ? 1 : on; return 0; }
 int flx_profile_get(flx_ctx *c, int k, double *ms, uint64_t *n) { NEED(c, k >= 0 && k < FLX_K_COUNT, "bad kernel id"); *ms = c->kMs[k]; *n = c->kLaunches[k]; return 0; }
 int flx_profile_reset(flx_ctx *c) { for (int k = 0; k < FLX_K_COUNT; k++) { c->kMs[k] = 0; c->kLaunches[k] = 0; } return 0; }
 int flx_trace_stats_enable(flx_ctx *c, int on) { ENTER(c, CALL_PEEK); c->statsOn = on != 0; return 0; }
@@ -1314,7 +1318,7 @@ int flx_set_counters(flx_ctx *c, const void *in32)
 {
     ENTER(c, CALL_OBSERVE);
     c->qs.extPend = 0;                                  // the caller's counters are complete
-    c->matQueuesEmpty = false;                          // ... and unknown here
+    c->matQueuesEmpty = false; c->raygenQueueEmpty = false;   // ... and unknown here
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->qs.counters, in32, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -154,8 +154,9 @@ enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FL
        FLX_K_LOGIC_FUSED = 8,  /* logic + the inlined material step as one pass (option "fuse"); FLX_K_MATERIALS then covers the rest */
        FLX_K_COUNT = 9 };
 /* on: 0 off | 1 time every kernel | 2 time only the two trace kernels (+ their span), as the reference does | 3 only the
- * extension kernel.  Each event pair costs a few microseconds of stream time, which shows at ~11 launches per 0.7 ms
- * iteration: level 1 costs 7 % of the throughput, level 3 about 1.5 %. */
+ * extension kernel | 4 the three kernels bench.py prices against a roof: extension, logic (the fused pass incl. its queue scan + scatter), shadow.
+ * Each event pair costs a few microseconds of stream time, which shows at ~11 launches per 0.7 ms
+ * iteration: level 1 costs 7 % of the throughput, level 3 about 1.5 % (at 1 M paths; at the bench's 8 M a quarter of that). */
 int flx_profile_enable(flx_ctx *ctx, int on);
 /* after flx_finish(): accumulated milliseconds and launch count since the last reset */
 int flx_profile_get(flx_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

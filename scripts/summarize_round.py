@@ -14,7 +14,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
-KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
+KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_shadow4s<", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
         "k_queue_scatter", "k_queue_scan")
 bench = {}
 try:
@@ -74,5 +74,18 @@ if ext:
          "extend_lanes_per_valu_instruction": (acc[ext]["SQ_THREAD_CYCLES_VALU"][0] / acc[ext]["SQ_INSTS_VALU"][0]) if acc[ext].get("SQ_INSTS_VALU", [0])[0] else None,
          "correction": "gfx950 guide: FETCH_SIZE = TCC_EA0_RDREQ x 64 B although the requests are 128 B -> read bytes = 128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B; write bytes = 64 x WRREQ_64B + 32 x the rest.  Fabric-side counts: Infinity-Cache hits are included, HBM proper is lower.",
          "extend_hbm_bytes_per_launch": t["read_bytes"] + t["write_bytes"] + sum(extra_k.values())}
+
+    def per_launch(keys):
+        """fabric bytes / VALU instructions / lanes per instruction of the dispatches of `keys` that make up ONE launch of the pass (e.g. the fused
+        logic pass = k_logic + k_queue_scan + k_queue_scatter: flx_wf_logic's timer covers all three)"""
+        ks = [k for k in keys if k in acc]
+        if not ks:
+            return None
+        by = sum(traffic[k]["read_bytes"] + traffic[k]["write_bytes"] for k in ks if k in traffic) or None
+        vi = sum(acc[k]["SQ_INSTS_VALU"][0] / max(1, acc[k]["SQ_INSTS_VALU"][1]) for k in ks if acc[k].get("SQ_INSTS_VALU", [0])[0])
+        tc = sum(acc[k]["SQ_THREAD_CYCLES_VALU"][0] / max(1, acc[k]["SQ_THREAD_CYCLES_VALU"][1]) for k in ks if acc[k].get("SQ_THREAD_CYCLES_VALU", [0])[0])
+        return {"kernels": ks, "hbm_bytes_per_launch": by, "valu_instructions_per_launch": vi or None, "lanes_per_valu_instruction": (tc / vi) if vi else None}
+    j["passes"] = {"extend": per_launch([ext]), "logic": per_launch(["k_logic", "k_queue_scan", "k_queue_scatter"]),
+                   "shadow": per_launch(["k_shadow4<false", "k_shadow4s<", "k_trace4r<true", "k_shadow<false>", "k_lightfix4"])}
     json.dump(j, open(os.path.join(prof, f"traffic_{wl}.json"), "w"), indent=1)
     print("wrote traffic_%s.json: %.4g bytes per launch" % (wl, j["extend_hbm_bytes_per_launch"]))

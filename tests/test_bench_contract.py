@@ -21,7 +21,7 @@ def test_bench_json_line_contract(tmp_path):
               "roofline", "cpu_baseline"):
         assert k in j, k
     assert j["unit"] == "Mrays/s" and j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 3 and j["higher_is_better"] is True
-    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"].startswith("synthetic") and "night.hdr" in j["data"]
     assert "workload" in j["config"] and "model" not in j["config"]
     assert j["value"] > 0 and j["ms_per_step"] > 0
     r = j["roofline"]
@@ -33,6 +33,11 @@ def test_bench_json_line_contract(tmp_path):
     assert r["traffic"] is None and r["achieved"] is None and r["frac"] is None and r["frac_source"] is None
     assert r["traffic_capture_stale_keys"] and "num_tasks" in r["traffic_capture_stale_keys"]
     assert 0.0 < r["frac_own"] < 1.5
+    # the other roofs: null without a capture as well, but the blocks are there and the three priced kernels are timed inside the timed region
+    assert r["valu"] is None and set(r["other_kernels"]) == {"logic", "shadow"}
+    for k, o in r["other_kernels"].items():
+        assert o["launch_ms"] > 0 and o["timed"] == "timed region" and o["hbm"]["frac"] is None and o["valu"] is None, (k, o)
+    assert "shadow_split" in r["capture_key"] and r["capture_key"]["library"] == "libfluctus_hip.so" and "gfx950" in r["capture_key"]["build_flags"]
     # protocol: settle >= 2 * maxBounces + 2 whatever --warmup says, five windows, headline = the median one
     assert j["settle_iterations"] >= 2 * j["config"]["max_bounces"] + 2 and j["settle_iterations"] >= j["warmup"]
     w = j["windows"]

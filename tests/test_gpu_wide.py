@@ -355,15 +355,39 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
     device is put back on the oracle's state as soon as a counter differs.  At a checkpoint (every fifth iteration, or the iteration a
     counter differs) the paths whose state differs are counted against the same 1e-5 budget and everything else must be bit-identical.  (Zero tolerance for the same chain: test_refill_kernels_are_bit_identical_to_thread_per_ray, device vs device.)
     FLX_SOAK_ITERS lengthens the run (default 15)."""
+    _bench_launch_chain_vs_oracle(workload, 1 << 20, int(os.environ.get("FLX_SOAK_ITERS", "15")))
+
+
+def test_bench_launch_chain_vs_oracle_at_bench_path_count():
+    """The same chain at bench.NUM_TASKS (8 M paths: the path count bench.py times -- two-level queue scan, other grids, the persistent grid : block
+    ratio of the timed run) on the headline workload: the device runs 10 iterations alone (deep paths in flight, stationary queue mix), the oracle
+    takes over its state, then 5 whole iterations of the untouched launch chain on both sides -- k_logic<FUSE, RAW> commits the RAW hit records of
+    8 M paths with nothing looking in between -- counters every iteration, the whole state at the end (round 4's verdict: "k_logic<1, true> at 8 M
+    has never been compared with anything but itself")."""
+    import bench
+    _bench_launch_chain_vs_oracle("kitchen", bench.NUM_TASKS, 5, start_iterations=10, tag="bench_path_count_")
+
+
+def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""):
     import bench
     d, p, env = bench.build_workload(name=workload)
-    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
-    iters = int(os.environ.get("FLX_SOAK_ITERS", "15"))
+    npix = int(p["width"]) * int(p["height"])
     g, o = _ctxs(d, p, n, env=env)
     assert g.get_option("refill_extend") > 0 and g.get_option("fuse") == 1 and g.get_option("extend_tree") == 4
     rays = ext_rays = forked = 0
+    cursor0 = 0
+    for _ in range(start_iterations):                     # the device alone: then the oracle takes over its state, queues (empty) and pixel cursor
+        c0 = driver.benchmark_iteration(g, npix)
+        cursor0 = (cursor0 + int(c0[Q.RAYGEN])) % npix
+    if start_iterations:
+        o.state_import(g.state_export())
+        o.pixel_index_reset(); o.pixel_index_update(npix, cursor0)
+        for c in (g, o):
+            c.clear_queues()
+        # the framebuffers differ from here on (the oracle's starts empty): compared as differences below
     skip = np.zeros(64, bool); skip[list(common.PAD_COLS)] = True; skip[COL.PHASE] = True
-    cursor = 0                                            # the host-side pixel cursor both contexts carry (replayed from the oracle's counts)
+    cursor = cursor0                                      # the host-side pixel cursor both contexts carry (replayed from the oracle's counts)
+    fb0 = g.read_pixels(0) if start_iterations else None
     common_state = [None, 0, 0]                           # oracle state, cursor, iteration count at the last point both sides were identical
     explained = []
 
@@ -453,8 +477,15 @@ def test_bench_launch_chain_vs_oracle_full_size(workload):
             checkpoint(f"after {it + 1} iterations", it + 1)
     assert forked <= max(1, int(FLIP_BUDGET * ext_rays)), (workload, forked, ext_rays)
     if not forked:
-        assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{workload}: framebuffers differ"
-    _report(f"bench_chain_vs_oracle_{workload}", {"paths": n, "iterations": iters, "rays": rays, "extension_rays": ext_rays,
+        pg, po = g.read_pixels(0), o.read_pixels(0)
+        if fb0 is not None:                               # what the compared iterations ADDED (counts exact; sums to the any-order bound on the totals)
+            assert np.array_equal(pg[:, 3] - fb0[:, 3], po[:, 3]), f"{workload}: splat counts differ"
+            # (every fp32 add onto an accumulated value A rounds by <= 6e-8 A: a few dozen splats per pixel -> 4e-6 of the totals)
+            err = np.abs((pg[:, :3] - fb0[:, :3]) - po[:, :3])
+            assert (err <= 1e-5 * np.abs(po[:, :3]) + 4e-6 * (np.abs(fb0[:, :3]) + np.abs(pg[:, :3])) + 1e-6).all(), f"{workload}: framebuffers differ (max {err.max()})"
+        else:
+            assert common.fb_close(pg, po), f"{workload}: framebuffers differ"
+    _report(f"bench_chain_vs_oracle_{tag}{workload}", {"paths": n, "iterations": iters, "rays": rays, "extension_rays": ext_rays,
                                                   "paths_forked_by_a_tie": forked, "forks_shown_to_be_ties_by_replay": len(explained)})
     g.close()
 

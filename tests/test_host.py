@@ -953,3 +953,17 @@ def test_sah_bvh_is_the_reference_builders_tree(tmp_path, scene):
     host.build_bvh(d, "sah")
     assert rn.size == d.nodes.size and np.array_equal(ri, d.indices)
     assert np.array_equal(rn.view(np.uint8), d.nodes.view(np.uint8))
+
+
+def test_night_env_fixture_tables_are_reproducible():
+    """tests/golden/night_env.npz (scripts/make_envmap_fixture.py): the reference's night.hdr as pixels; bench.night_env() rebuilds the alias / pdf tables
+    with host/envmap.cpp and checks them against the digest taken when the fixture was made; pdf[0] is the value SURVEY 8(c) records from the reference's own
+    EnvironmentMap (0.00115893)."""
+    import bench
+    e = bench.night_env()
+    assert (e.w, e.h) == (512, 256)
+    assert abs(float(e.pdf[0]) - 0.00115893) < 1e-7
+    assert e.prob.size == 512 * 256 and (e.prob <= 1.0).all() and (e.alias >= 0).all() and (e.alias < e.prob.size).all()
+    if os.path.isdir(REF):            # build container: identical to loading the .hdr itself
+        f = host.load_envmap(REF + "/env_maps/night.hdr")
+        assert np.array_equal(f.rgb, e.rgb) and np.array_equal(f.prob, e.prob) and np.array_equal(f.alias, e.alias) and np.array_equal(f.pdf, e.pdf)
