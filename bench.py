@@ -535,22 +535,27 @@ def main():
         ach, src = traffic / launch_s / 1e9, "counters"
     else:
         ach, src = None, None
-    # ---- the instruction-issue roof.  A wave64 VALU instruction occupies its SIMD's 16-lane ALU for 4 cycles (scripts/ubench/valu_pairs*.hip measured
-    # 4.0-4.3 SIMD-cycles per dependent-free instruction, single-pipe ops included), so a kernel cannot retire more than SIMDs x clock / 4 wave-instructions
-    # per second whatever its lanes do: issue_frac = instructions x 4 / (SIMDs x clock x launch time).  The traversal kernels sit near 0.8 of THAT roof
-    # at half their lanes idle -- HBM (frac, above) is not what bounds them on a cache-resident tree -- while the logic pass is the one HBM-bound kernel.
+    # ---- the instruction-issue roof.  gfx950's SIMD has two 16-lane VALU pipes (scripts/ubench/valu_*.hip, profiles/r03_ubench_*): plain mul / add / fmac / logic
+    # instructions issue on either (2.1-2.4 SIMD-cycles per wave64 instruction), compares, selects, min / max, shifts and conversions on ONE of them (4.0-4.4).
+    # A kernel cannot retire more than SIMDs x clock / c wave-instructions per second with c between those two:
+    #     issue_frac     = instructions x 4 / (SIMDs x clock x launch time)   (all single-pipe: the TRAVERSAL kernels' mix -- 3.97 measured on k_extend4)
+    #     issue_frac_min = instructions x 2 / ...                              (all dual-pipe: what even a pure-arithmetic mix cannot beat)
+    # `bound` of a traversal kernel compares its HBM fraction with issue_frac; of the logic pass (arithmetic-heavy, mix not measured) with issue_frac_min, i.e.
+    # it says "valu-issue" only when the instruction stream would saturate the SIMDs even at the dual-pipe rate.  (rocprof's derived VALUBusy = SQ_ACTIVE_INST_VALU
+    # x 4 / SIMDs / cycles assumes 4 cycles for every instruction and exceeds 100 % on the all-types logic pass: not used.)
     prop = torch.cuda.get_device_properties(local_rank)
     simds = int(prop.multi_processor_count) * 4
     clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-    CYC = 4.0
+    CYC, CYC_MIN = 4.0, 2.0
 
     def valu_block(insts, lanes, secs):
         if not insts or not secs:
             return None
-        return {"instructions_per_launch": insts, "cycles_per_instruction": CYC, "simds": simds, "clock_GHz": clock_hz / 1e9,
-                "issue_frac": insts * CYC / (simds * clock_hz * secs), "lanes_per_instruction": lanes, "useful_lane_frac": (lanes / 64.0) if lanes else None}
+        return {"instructions_per_launch": insts, "cycles_per_instruction": {"single_pipe": CYC, "dual_pipe": CYC_MIN}, "simds": simds, "clock_GHz": clock_hz / 1e9,
+                "issue_frac": insts * CYC / (simds * clock_hz * secs), "issue_frac_min": insts * CYC_MIN / (simds * clock_hz * secs),
+                "lanes_per_instruction": lanes, "useful_lane_frac": (lanes / 64.0) if lanes else None}
 
-    def pass_block(name, prof_keys, label):
+    def pass_block(name, prof_keys, label, traversal):
         pb = passes.get(name) or {}
         ms, n = 0.0, 0
         for k_ in prof_keys:
@@ -560,12 +565,12 @@ def main():
         by = pb.get("hbm_bytes_per_launch")
         hb = (by / secs / 1e9) if (by and secs) else None
         vb = valu_block(pb.get("valu_instructions_per_launch"), pb.get("lanes_per_valu_instruction"), secs)
-        fr = {"hbm": (hb / HBM_PEAK_GBS) if hb else None, "valu": vb["issue_frac"] if vb else None}
+        fr = {"hbm": (hb / HBM_PEAK_GBS) if hb else None, "valu-issue": (vb["issue_frac"] if traversal else vb["issue_frac_min"]) if vb else None}
         best = max((v, k_) for k_, v in fr.items() if v is not None)[1] if any(v is not None for v in fr.values()) else None
         return {"kernel": label, "launch_ms": (secs * 1e3) if secs else None, "timed": ("timed region" if prof_keys[0] not in untimed else "extra untimed pass"),
                 "bound": best, "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["hbm"], "traffic": by}, "valu": vb}
-    other = {"logic": pass_block("logic", ["logic_fused", "logic"], "logic (+ the inlined material step) + queue scan + scatter: k_logic<FUSE, RAW>, k_queue_scan, k_queue_scatter"),
-             "shadow": pass_block("shadow", ["shadow"], "traceShadow (k_shadow4: 4-wide quantised tree, thread per ray)" if not ctx.get_option("shadow_split") else "traceShadow (k_shadow4s: tail-split)")}
+    other = {"logic": pass_block("logic", ["logic_fused", "logic"], "logic (+ the inlined material step) + queue scan + scatter: k_logic<FUSE, RAW>, k_queue_scan, k_queue_scatter", False),
+             "shadow": pass_block("shadow", ["shadow"], "traceShadow (k_shadow4: 4-wide quantised tree, thread per ray)" if not ctx.get_option("shadow_split") else "traceShadow (k_shadow4s: tail-split)", True)}
     ext_valu = valu_block(traffic_valu, traffic_lanes, launch_s if launch_s > 0 else None)
     ext_hbm_frac = (ach / HBM_PEAK_GBS) if ach is not None else None
     ext_bound = "hbm"

@@ -1,0 +1,9 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -x -p no:cacheprovider 2>&1 | tail -6 > gpurun_out/r05_mlp_tests.log
+timeout 900 python -m pytest tests/test_gpu_wide.py -q -x -p no:cacheprovider -k "bench_launch_chain or default_path_free_run" 2>&1 | tail -6 >> gpurun_out/r05_mlp_tests.log
+cat gpurun_out/r05_mlp_tests.log
+bash scripts/ab.sh "--workload kitchen" mlp0 shipped > gpurun_out/r05_logic_mlp_ab.txt 2>&1
+bash scripts/ab.sh "--workload conference" mlp0 shipped >> gpurun_out/r05_logic_mlp_ab.txt 2>&1
+cat gpurun_out/r05_logic_mlp_ab.txt

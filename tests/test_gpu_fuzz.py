@@ -112,8 +112,19 @@ def test_call_sequence_fuzz(separate_queues, seed):
         c.pixel_index_reset(); c.pixel_index_update(npix, cursor)
     rng = np.random.RandomState(seed)
     covered = set()
+    covered_order = set()                              # (ext_order, phase, call)
     exported_raw = 0
     nobs = 0
+
+    def queue_equal(q, m, what):
+        """Queue q against the oracle's.  The extension queue of a fused pass with ext_order 1 / 2 lists the same paths in path-id order instead of
+        one segment per material queue (the reference's own order is whatever its atomic_inc produces): compared as a SET then, and -- the point
+        of ext_order 2 -- every slot below the counter must hold a path (no gap left for a genRays that does not append: round 4's advisor)."""
+        qa, qb = g.queue_read(q)[:m], o.queue_read(q)[:m]
+        if q == Q.EXTENSION and g.get_option("ext_order") != 0:
+            assert np.array_equal(np.sort(qa), np.sort(qb)), f"{what}: extension queue holds different paths"
+        else:
+            assert np.array_equal(qa, qb), f"{what}: queue {q} differs"
 
     def compare(what, queues=True):
         nonlocal exported_raw, nobs
@@ -123,24 +134,24 @@ def test_call_sequence_fuzz(separate_queues, seed):
         assert (cg == co).all(), f"{what}: counters {cg} vs {co}"
         if queues:
             for q in range(8):
-                m = int(co[q])
-                assert np.array_equal(g.queue_read(q)[:m], o.queue_read(q)[:m]), f"{what}: queue {q} differs"
+                queue_equal(q, int(co[q]), what)
         sg = g.state_export()
         fails = common.state_diff(sg, o.state_export(), 0.0, 0.0)
         assert not fails, f"{what}: " + "; ".join(fails[:4])
         hi = sg.view(np.uint32)[COL.HIT_I]
         exported_raw += int((((hi >> 30) & 3) == 1).sum())
 
-    def run(seq, fuse_set, what, check_each=False):
+    def run(seq, fuse_set, ext_order, what, check_each=False):
         nonlocal cursor
         g.set_option("fuse", 1); g.set_option("extend_tree", 4); g.set_option("refill_extend", 16 | (32 << 8)); g.set_option("overlap", 2)
         g.set_option("shadow_tree", 4); g.set_option("refill_shadow", 0)
-        g.set_option("fuse_set", fuse_set); g.set_option("ext_order", 0)
+        g.set_option("fuse_set", fuse_set); g.set_option("ext_order", ext_order)
         for c in (g, o):
             c.set_params(p)
         for k, op in enumerate(seq):
             ph = g.get_option("phase")
             covered.add((ph, op[0] if op[0] != "opt" else "opt:" + op[1]))
+            covered_order.add((ext_order, ph & 7, op[0]))
             if op[0] == "logic":
                 for c in (g, o): c.wf_logic(bool(op[1]))
             elif op[0] == "raygen":
@@ -171,8 +182,7 @@ def test_call_sequence_fuzz(separate_queues, seed):
             elif op[0] == "export":
                 compare(f"{what} step {k} (export)", queues=False)
             elif op[0] == "qread":
-                m = int(np.array(o.get_counters())[op[1]])
-                assert np.array_equal(g.queue_read(op[1])[:m], o.queue_read(op[1])[:m]), f"{what} step {k}: queue {op[1]}"
+                queue_equal(op[1], int(np.array(o.get_counters())[op[1]]), f"{what} step {k}")
             elif op[0] == "pixels":
                 if not check_each:                     # (a replay adds its samples a second time on both sides: still equal, but skip the noise)
                     assert common.fb_close(g.read_pixels(0), o.read_pixels(0)), f"{what} step {k}: framebuffers differ"
@@ -181,7 +191,7 @@ def test_call_sequence_fuzz(separate_queues, seed):
             elif op[0] == "opt":
                 g.set_option(op[1], op[2])
                 if op[1] == "fuse_set":
-                    g.set_option("ext_order", 0)
+                    g.set_option("ext_order", ext_order)          # (the sequence's order stays whatever the pass inlines)
             elif op[0] == "pixidx":
                 for c in (g, o): c.pixel_index_update(npix, op[1])
                 cursor = (cursor + op[1]) % npix
@@ -192,14 +202,17 @@ def test_call_sequence_fuzz(separate_queues, seed):
     for s in range(N_SEQ):
         seq = _gen_sequence(rng)
         fuse_set = int(rng.choice([1, 31]))
+        # the extension-queue order of the fused pass: 0 the separate kernels' segments | 1 continuing paths by id | 2 merged with the regenerated ones
+        # (the shipped default of the diffuse-only pass: the scatter writes the regenerated paths' entries and the deferred genRays must not append)
+        ext_order = int(rng.choice([0, 1, 2]))
         # every sequence starts from the oracle's current state, queues cleared
         for c in (g, o):
             c.clear_queues()
         common.sync(g, o)
         start, cursor0 = o.state_export(), cursor
-        what = f"sequence {s} (fuse_set {fuse_set}) {seq}"
+        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}) {seq}"
         try:
-            run(seq, fuse_set, what)
+            run(seq, fuse_set, ext_order, what)
         except AssertionError:
             # locate the call: same sequence from the same state, everything compared after every call
             for c in (g, o):
@@ -207,7 +220,7 @@ def test_call_sequence_fuzz(separate_queues, seed):
             cursor = cursor0
             for c in (g, o):
                 set_cursor(c)
-            run(seq, fuse_set, what, check_each=True)
+            run(seq, fuse_set, ext_order, what, check_each=True)
             raise
     assert exported_raw == 0, f"{exported_raw} RAW hit records were exported"
     phases = sorted({c[0] for c in covered})
@@ -219,4 +232,10 @@ def test_call_sequence_fuzz(separate_queues, seed):
         by_call.setdefault(call, set()).add(ph)
     for call in ("logic", "raygen", "materials", "extend", "shadow", "clear", "export", "counters", "params"):
         assert len(by_call.get(call, ())) >= 3, (call, by_call.get(call))
+    # ... and the chain calls under every extension-queue order, each from at least three phases (ext_order 2 couples the fused scatter with the
+    # deferred genRays: api.hip extOrderFor / runRaygen)
+    for order in (0, 1, 2):
+        for call in ("logic", "raygen", "materials", "extend", "clear", "end_iter"):
+            phs = {ph for (eo, ph, c_) in covered_order if eo == order and c_ == call}
+            assert len(phs) >= (3 if call in ("logic", "raygen", "materials", "extend") else 2), (order, call, phs)
     g.close()
