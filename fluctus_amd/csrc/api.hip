@@ -341,13 +341,13 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if ((e = hipHostMalloc((void **)&c->pinnedMk, 16 * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
     // dummy 1x1 black environment map (reference: CLContext::setupScene, src/clcontext.cpp:513-518)
     {
-        float4 *rgba; float *prob, *pdf; int *alias;
-        if (dalloc(c, c->envAllocs, &rgba, 1) || dalloc(c, c->envAllocs, &prob, 1) || dalloc(c, c->envAllocs, &pdf, 1) || dalloc(c, c->envAllocs, &alias, 1))
+        float4 *rgba, *rec; float *pdf;
+        if (dalloc(c, c->envAllocs, &rgba, 1) || dalloc(c, c->envAllocs, &rec, 1) || dalloc(c, c->envAllocs, &pdf, 1))
             return fail("hipMalloc(env)", hipErrorOutOfMemory);
-        float one = 1.0f;
-        (void)hipMemsetAsync(rgba, 0, 16, c->stream); (void)hipMemsetAsync(alias, 0, 4, c->stream);
-        (void)hipMemcpyAsync(prob, &one, 4, hipMemcpyHostToDevice, c->stream); (void)hipMemcpyAsync(pdf, &one, 4, hipMemcpyHostToDevice, c->stream);
-        c->sc.envRGBA = rgba; c->sc.probTable = prob; c->sc.pdfTable = pdf; c->sc.aliasTable = alias; c->sc.envW = c->sc.envH = 1;
+        const float one = 1.0f; const float4 rec1 = make_float4(1.0f, 0.0f /* alias 0 */, 1.0f, 1.0f);
+        (void)hipMemsetAsync(rgba, 0, 16, c->stream);
+        (void)hipMemcpy(rec, &rec1, 16, hipMemcpyHostToDevice); (void)hipMemcpy(pdf, &one, 4, hipMemcpyHostToDevice);
+        c->sc.envRGBA = rgba; c->sc.aliasRec = rec; c->sc.pdfTable = pdf; c->sc.envW = c->sc.envH = 1;
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     *out = c;
@@ -609,13 +609,20 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
     for (size_t i = 0; i < n; i++) rgba[i] = make_float4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 1.0f);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     freeAll(c->envAllocs);
-    float4 *dR; float *dP, *dF; int *dA;
-    if (dalloc(c, c->envAllocs, &dR, n) || dalloc(c, c->envAllocs, &dP, n) || dalloc(c, c->envAllocs, &dF, n) || dalloc(c, c->envAllocs, &dA, n)) return 1;
+    // the three sampling tables of the reference (src/envmap.cpp:31-114) merged into one record per texel (flx_device.h: aliasRec); the plain pdf table
+    // stays for env_map_pdf.  An alias outside the table (a malformed upload) is clamped like the kernel's own index clamp.
+    std::vector<float4> rec(n);
+    for (size_t i = 0; i < n; i++) {
+        int a = alias[i]; if (a < 0) a = 0; if ((size_t)a >= n) a = (int)n - 1;
+        float af; memcpy(&af, &a, 4);
+        rec[i] = make_float4(prob[i], af, pdf[i], pdf[a]);
+    }
+    float4 *dR, *dRec; float *dF;
+    if (dalloc(c, c->envAllocs, &dR, n) || dalloc(c, c->envAllocs, &dRec, n) || dalloc(c, c->envAllocs, &dF, n)) return 1;
     HIPCHK(c, hipMemcpy(dR, rgba.data(), n * 16, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dP, prob, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dRec, rec.data(), n * 16, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dF, pdf, n * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dA, alias, n * 4, hipMemcpyHostToDevice));
-    c->sc.envRGBA = dR; c->sc.probTable = dP; c->sc.pdfTable = dF; c->sc.aliasTable = dA; c->sc.envW = w; c->sc.envH = h;
+    c->sc.envRGBA = dR; c->sc.aliasRec = dRec; c->sc.pdfTable = dF; c->sc.envW = w; c->sc.envH = h;
     return 0;
 }
 

@@ -97,8 +97,10 @@ struct Scene {
     float wideClamp;              // bound of |1 / dir| in the wide node test: 2^100, or 2^64 for scenes beyond +-2^26 (flx_trace4.h: WRay::setup)
     // environment map
     const float4 *envRGBA;
-    const float *probTable, *pdfTable;
-    const int *aliasTable;
+    const float *pdfTable;
+    const float4 *aliasRec;       // {probTable[i], aliasTable[i] (int bits), pdfTable[i], pdfTable[aliasTable[i]]}: the alias-method sample of
+                                  // sample_env_alias is ONE 16-byte gather instead of three dependent ones at random i (round 5: these gathers were
+                                  // 18 % of the fused logic pass, profiles/r05_logic_probes_ab.txt); built at flx_upload_envmap, values copied bit for bit
     int envW, envH;
 };
 

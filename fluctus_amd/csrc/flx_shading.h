@@ -97,9 +97,10 @@ __device__ __forceinline__ void sample_env_alias(const Scene &sc, float rnd, f3 
     float r = rnd * (float)width * (float)height;
     int i = (int)floorf(r);
     if (i > width * height - 1) i = width * height - 1;
-    float mProb = sc.probTable[i];
-    int uvInd = (r - (float)i < mProb) ? i : sc.aliasTable[i];
-    float pdf_uv = sc.pdfTable[uvInd];
+    const float4 rec = sc.aliasRec[i];                              // {prob[i], alias[i], pdf[i], pdf[alias[i]]} (flx_device.h)
+    const bool own = r - (float)i < rec.x;
+    int uvInd = own ? i : __float_as_int(rec.y);
+    float pdf_uv = own ? rec.z : rec.w;
     int uInd = uvInd % width, vInd = uvInd / width;
     float u = ((float)uInd + 0.5f) / (float)width;
     float v = ((float)vInd + 0.5f) / (float)height;

@@ -13,9 +13,12 @@ __device__ __forceinline__ float4 rd4(const float4 *p) { v4f v = __builtin_nonte
 __device__ __forceinline__ void wr4(float4 *p, float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, (v4f *)p); }
 struct St { float4 *rec[12]; uint32_t *blocked; float *pick; uint8_t *member; const float4 *shade; uint32_t nshade; uint32_t n; };
 
-template <int MODE, int W>
+template <int MODE_, int W>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void k(St st)
 {
+    constexpr int MODE = MODE_ % 10;
+    constexpr bool TEMPORAL = MODE_ >= 10;        // MODE_ 1x: plain (temporal, write-back) stores instead of non-temporal ones
+    auto wr4 = [](float4 *p, float4 v) { if (TEMPORAL) *p = v; else ::wr4(p, v); };
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= st.n) return;
     const uint32_t b = st.blocked[gid]; const float pk = st.pick[gid];
@@ -31,8 +34,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) voi
         acc.z += a.x + c.y + d.z + e.w;
     }
     const int NW = MODE == 3 ? 10 : MODE == 4 ? 8 : 12;
+    // MODE 5 / 6: 21 % of the lanes (the terminating paths; hash of the id, so the holes fall on random lanes) store only 3 of the 12 records --
+    // partial 128-byte lines and partial 32-byte sectors in the other nine streams; MODE 6 adds their four float atomics on a 33 MB framebuffer
+    const bool term = (MODE == 5 || MODE == 6 || MODE == 7) && ((gid * 2654435761u) >> 8) % 100u < 21u;
     #pragma unroll
-    for (int r = 0; r < NW; r++) wr4(st.rec[r] + gid, make_float4(acc.x + r, acc.y, acc.z, r == 4 ? r4.z : acc.w));
+    for (int r = 0; r < NW; r++) if (!term || r == 4 || r == 5 || r == 6) wr4(st.rec[r] + gid, make_float4(acc.x + r, acc.y, acc.z, r == 4 ? r4.z : acc.w));
+    if (MODE == 7) {       // the union of two DIVERGENT partial stores covers every line: does the L2 merge them before they reach HBM?
+        const bool t2 = ((gid * 2654435761u) >> 8) % 100u < 21u;
+        if (t2) {
+            #pragma unroll
+            for (int r = 0; r < 12; r++) if (!(r == 4 || r == 5 || r == 6)) wr4(st.rec[r] + gid, make_float4(acc.y + r, acc.x, acc.z, acc.w));
+        }
+    }
+    if (MODE == 6 && term) {
+        float *px = (float *)st.rec[7] + (size_t)((gid * 40503u) % 2073600u) * 4;
+        unsafeAtomicAdd(px, acc.x); unsafeAtomicAdd(px + 1, acc.y); unsafeAtomicAdd(px + 2, acc.z); unsafeAtomicAdd(px + 3, 1.0f);
+    }
     st.member[gid] = (uint8_t)(b + 1u);
 }
 
@@ -68,5 +85,11 @@ int main()
     RUN(1, 5, rd0 + wr12 + 0.26 * 64); RUN(1, 8, rd0 + wr12 + 0.26 * 64);
     RUN(2, 5, rd0 + wr12 + 0.26 * 64); RUN(2, 8, rd0 + wr12 + 0.26 * 64);
     RUN(3, 5, rd0 + 10 * 16 + 1 + 0.26 * 64); RUN(4, 5, rd0 + 8 * 16 + 1 + 0.26 * 64);
+    RUN(2, 5, rd0 + wr12 + 0.26 * 64);
+    RUN(5, 5, rd0 + (0.79 * 12 + 0.21 * 3) * 16 + 1 + 0.26 * 64); RUN(6, 5, rd0 + (0.79 * 12 + 0.21 * 3) * 16 + 1 + 0.26 * 64);
+    RUN(2, 5, rd0 + wr12 + 0.26 * 64); RUN(5, 5, rd0 + (0.79 * 12 + 0.21 * 3) * 16 + 1 + 0.26 * 64);
+    RUN(7, 5, rd0 + wr12 + 0.26 * 64); RUN(2, 5, rd0 + wr12 + 0.26 * 64); RUN(7, 5, rd0 + wr12 + 0.26 * 64);
+    RUN(12, 5, rd0 + wr12 + 0.26 * 64); RUN(15, 5, rd0 + (0.79 * 12 + 0.21 * 3) * 16 + 1 + 0.26 * 64); RUN(17, 5, rd0 + wr12 + 0.26 * 64);
+    RUN(12, 5, rd0 + wr12 + 0.26 * 64); RUN(15, 5, rd0 + (0.79 * 12 + 0.21 * 3) * 16 + 1 + 0.26 * 64); RUN(17, 5, rd0 + wr12 + 0.26 * 64);
     return 0;
 }
