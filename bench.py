@@ -141,7 +141,7 @@ def capture_key(args, ctx, p, C=1):
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
             "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"),
-            "shadow_split": ctx.get_option("shadow_split"),
+            "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"),
             # which BINARY ran: the shipped library or an A/B variant (FLX_HIP_LIB, e.g. a -DFLX_LAB build of the same sources), and its compile flags
             "library": os.path.basename(os.environ.get("FLX_HIP_LIB") or "libfluctus_hip.so"), "build_flags": " ".join(build.HIP_FLAGS),
             "source_hash": build.source_hash()}
@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--fuse-set", type=int, default=0, choices=(0, 1, 31), help="BSDF types the fused pass inlines: 0 = what flx_upload_scene chose, 1 diffuse, 31 all")
     ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
+    ap.add_argument("--regen", type=int, default=-1, help="in-kernel regeneration of terminating paths by the fused logic pass (option regen): 0 off (genRays kernel), 1 on, -1 = library default")
     ap.add_argument("--shadow-split", type=int, default=-1, help="tail splitting of the any-hit kernel: node-visit budget of the pass over the queue | budget of a second pass << 8; 0 = off, -1 = library default")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
@@ -264,6 +265,8 @@ def main():
             c_.set_option("refill_shadow", args.refill_shadow)
         if args.shadow_split >= 0:
             c_.set_option("shadow_split", args.shadow_split)
+        if args.regen >= 0:
+            c_.set_option("regen", args.regen)
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene

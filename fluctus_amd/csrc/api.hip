@@ -23,7 +23,11 @@ void launch_shadow4_split(hipStream_t, const State &, const Queues &, const Scen
 uint32_t shadow_split_lists(); uint32_t shadow_split_count_words();
 void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
-void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int);
+void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int,
+                  unsigned long long *, uint32_t, int, int, uint32_t *);
+void launch_env_nee_table(hipStream_t, const Scene &, float4 *, uint32_t);
+int logic_can_regenerate();
+uint32_t logic_lookback_words(uint32_t numTasks);
 void launch_materialise(hipStream_t, const State &, const Scene &, const flx_render_params &, uint32_t);
 void launch_materials(hipStream_t, const State &, const Queues &, const Scene &, uint32_t);
 void launch_materials_after_fused(hipStream_t, const State &, const Queues &, const Scene &, uint32_t, int);
@@ -91,6 +95,10 @@ struct flx_ctx {
     uint32_t hostPixelIdx = 0;
     // logic aux
     uint8_t *member = nullptr; uint32_t *blockCounts = nullptr, *blockOffsets = nullptr;
+    // in-kernel regeneration of the fused RAW pass (logic.hip: REGEN): look-back status words (one per wave, epoch-stamped: never reset), launch counter,
+    // device error flag (a look-back that gave up), option "regen" (1: on where the pass allows it), and whether the LAST fused pass regenerated its
+    // terminating paths itself -- then the genRays of the chain is not launched (flx_wf_materials)
+    unsigned long long *lookback = nullptr; uint32_t logicEpoch = 0; uint32_t *logicError = nullptr; int regenOpt = 0; bool regenDone = false;      // (off by default: profiles/r05_regen_ab.txt -- the look-back costs more than genRays)
     // trace aux
     uint32_t *spill = nullptr;
     unsigned long long *stats = nullptr;   // device, 16 counters
@@ -290,8 +298,16 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     // (stream priorities were tried: a high-priority shadow stream keeps the extension kernel at its undisturbed 0.86 ms and inflates
     //  the material kernel instead, a high-priority main stream changes nothing -- resident waves are not displaced; the step time
     //  stays within 0.7 % in every combination, so both streams have the default priority)
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+#ifndef FLX_STREAM_PRIO          // 0: both streams at the default priority | 1: the main stream (logic -> genRays -> materials -> closest hit) above the any-hit stream
+#define FLX_STREAM_PRIO 0
+#endif
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int pMain = FLX_STREAM_PRIO ? greatest : 0, pSecond = FLX_STREAM_PRIO ? least : 0;
+        if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pMain)) != hipSuccess) return fail("hipStreamCreate", e);
+        if ((e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, pSecond)) != hipSuccess) return fail("hipStreamCreate", e);
+    }
     if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
@@ -317,6 +333,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     const size_t auxStride = logic_aux_stride(num_tasks);          // per list, padded for the scan kernel's uint4 accesses
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * auxStride) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * auxStride))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
+    if (dalloc(c, c->fixedAllocs, &c->lookback, (size_t)logic_lookback_words(N)) || dalloc(c, c->fixedAllocs, &c->logicError, 1)) return fail("hipMalloc(lookback)", hipErrorOutOfMemory);
+    (void)hipMemsetAsync(c->lookback, 0, (size_t)logic_lookback_words(N) * 8, c->stream);
+    (void)hipMemsetAsync(c->logicError, 0, 4, c->stream);
     (void)hipMemsetAsync(c->blockCounts, 0, (size_t)7 * auxStride * 4, c->stream);      // the pad behind each list's counts stays zero
     (void)hipMemsetAsync(c->blockOffsets, 0, (size_t)7 * auxStride * 4, c->stream);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount; }
@@ -341,13 +360,15 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     if ((e = hipHostMalloc((void **)&c->pinnedMk, 16 * c->pinnedSlots)) != hipSuccess) return fail("hipHostMalloc", e);
     // dummy 1x1 black environment map (reference: CLContext::setupScene, src/clcontext.cpp:513-518)
     {
-        float4 *rgba, *rec; float *pdf;
+        float4 *rgba; float2 *rec; float *pdf;
         if (dalloc(c, c->envAllocs, &rgba, 1) || dalloc(c, c->envAllocs, &rec, 1) || dalloc(c, c->envAllocs, &pdf, 1))
             return fail("hipMalloc(env)", hipErrorOutOfMemory);
-        const float one = 1.0f; const float4 rec1 = make_float4(1.0f, 0.0f /* alias 0 */, 1.0f, 1.0f);
+        const float one = 1.0f; const float2 rec1 = make_float2(1.0f, 0.0f /* alias 0 */);
         (void)hipMemsetAsync(rgba, 0, 16, c->stream);
-        (void)hipMemcpy(rec, &rec1, 16, hipMemcpyHostToDevice); (void)hipMemcpy(pdf, &one, 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(rec, &rec1, 8, hipMemcpyHostToDevice); (void)hipMemcpy(pdf, &one, 4, hipMemcpyHostToDevice);
         c->sc.envRGBA = rgba; c->sc.aliasRec = rec; c->sc.pdfTable = pdf; c->sc.envW = c->sc.envH = 1;
+        float4 *nee; if (dalloc(c, c->envAllocs, &nee, 2)) return fail("hipMalloc(env)", hipErrorOutOfMemory);
+        launch_env_nee_table(c->stream, c->sc, nee, 1u); c->sc.neeRec = nee;
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("hipStreamSynchronize", e);
     *out = c;
@@ -609,20 +630,24 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
     for (size_t i = 0; i < n; i++) rgba[i] = make_float4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 1.0f);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     freeAll(c->envAllocs);
-    // the three sampling tables of the reference (src/envmap.cpp:31-114) merged into one record per texel (flx_device.h: aliasRec); the plain pdf table
-    // stays for env_map_pdf.  An alias outside the table (a malformed upload) is clamped like the kernel's own index clamp.
-    std::vector<float4> rec(n);
+    // the probability and alias tables of the reference (src/envmap.cpp:31-114) merged into one record per texel (flx_device.h: aliasRec); the pdf table
+    // stays as it is (env_map_pdf, and the per-texel NEE table below is built from it).  An alias outside the table (a malformed upload) is clamped like the kernel's own index clamp.
+    std::vector<float2> rec(n);
     for (size_t i = 0; i < n; i++) {
         int a = alias[i]; if (a < 0) a = 0; if ((size_t)a >= n) a = (int)n - 1;
         float af; memcpy(&af, &a, 4);
-        rec[i] = make_float4(prob[i], af, pdf[i], pdf[a]);
+        rec[i] = make_float2(prob[i], af);
     }
-    float4 *dR, *dRec; float *dF;
+    float4 *dR; float2 *dRec; float *dF;
     if (dalloc(c, c->envAllocs, &dR, n) || dalloc(c, c->envAllocs, &dRec, n) || dalloc(c, c->envAllocs, &dF, n)) return 1;
     HIPCHK(c, hipMemcpy(dR, rgba.data(), n * 16, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dRec, rec.data(), n * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dRec, rec.data(), n * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dF, pdf, n * 4, hipMemcpyHostToDevice));
     c->sc.envRGBA = dR; c->sc.aliasRec = dRec; c->sc.pdfTable = dF; c->sc.envW = w; c->sc.envH = h;
+    float4 *dNee; if (dalloc(c, c->envAllocs, &dNee, 2 * n)) return 1;
+    launch_env_nee_table(c->stream, c->sc, dNee, (uint32_t)n); HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sc.neeRec = dNee;
     return 0;
 }
 
@@ -654,10 +679,11 @@ int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); c->raygenQue
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
 static void flushExtIfPending(flx_ctx *c, uint32_t bits) { if (c->qs.extPend & bits) flushExt(c); }
-static int runRaygen(flx_ctx *c, int appendExt = 1)
+static int runRaygen(flx_ctx *c, int appendExt = 1, bool alreadyDone = false)
 {
     flushExtIfPending(c, 1u << FLX_Q_RAYGEN);
-    { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params, appendExt); }
+    // alreadyDone: the fused RAW pass of this chain regenerated the paths (and appended them) itself: only the bookkeeping of the call is left
+    if (!alreadyDone) { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params, appendExt); }
     c->qs.extPend |= 1u << FLX_Q_RAYGEN;
     if (c->eagerBump) flushExt(c);
     LAUNCHED(c);
@@ -692,7 +718,14 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 #ifdef FLX_LAB_NOJOIN
     if (c->labIter >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evLab[c->labIter & 1u], 0));      // the shadow kernel BEFORE the last one
 #endif
-    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, extOrderFor(c, fused, raygenFirst), raw); }
+    // REGEN: the RAW pass regenerates its terminating paths itself when their index in the raygen queue is their rank among the terminating paths,
+    // i.e. when the raygen queue was empty before this pass (as for ext_order 2); the genRays call of the chain then launches nothing (flx_wf_materials)
+    const int order = extOrderFor(c, fused, raygenFirst);
+    const int regen = (raw && c->regenOpt && logic_can_regenerate() && c->raygenQueueEmpty && c->fr.localPixels > 0) ? 1 : 0;
+    c->regenDone = regen != 0;
+    if (++c->logicEpoch == 0u) c->logicEpoch = 1u;     // (epoch 0 = the zero-filled words of a fresh context)
+    { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, order, raw,
+                                                                                c->lookback, c->logicEpoch, regen, order == 2 ? 0 : 1, c->logicError); }
     LAUNCHED(c);
     c->matQueuesEmpty = false; c->raygenQueueEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -834,7 +867,8 @@ int flx_wf_materials(flx_ctx *c)
         HIPCHK(c, hipSetDevice(c->device));
         const int order = extOrderFor(c, c->fuseSet, withRaygen);
         if (runLogic(c, c->pendFirst, c->fuseSet, withRaygen)) return 1;
-        if (withRaygen && runRaygen(c, order == 2 ? 0 : 1)) return 1;
+        if (withRaygen && runRaygen(c, order == 2 ? 0 : 1, c->regenDone)) return 1;
+        c->regenDone = false;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
         { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), order); }
         LAUNCHED(c);
@@ -905,6 +939,10 @@ int flx_finish(flx_ctx *c)
     ENTER(c, CALL_QUIET);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->logicEpoch) {                                 // a look-back of the fused pass that gave up (logic.hip): fail loudly, never silently wrong pixels
+        uint32_t e = 0; HIPCHK(c, hipMemcpy(&e, c->logicError, 4, hipMemcpyDeviceToHost));
+        if (e) { c->err = "k_logic: the in-kernel regeneration's look-back timed out"; return 1; }
+    }
     for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
     c->pending.clear();
     for (auto &p : c->pendingMk) memcpy(p.first, c->pinnedMk + 4 * p.second, 16);
@@ -1337,6 +1375,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
     if (name && strcmp(name, "ext_order") == 0 && value >= 0 && value <= 2) { c->extOrder = value; return 0; }
+    if (name && strcmp(name, "regen") == 0 && (value == 0 || value == 1)) { c->regenOpt = value; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { ENTER(c, CALL_OBSERVE); c->overlapOpt = value; pickSchedule(c); return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { ENTER(c, CALL_OBSERVE); c->shadowTree = value; return 0; }
@@ -1367,7 +1406,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;

@@ -98,9 +98,14 @@ struct Scene {
     // environment map
     const float4 *envRGBA;
     const float *pdfTable;
-    const float4 *aliasRec;       // {probTable[i], aliasTable[i] (int bits), pdfTable[i], pdfTable[aliasTable[i]]}: the alias-method sample of
-                                  // sample_env_alias is ONE 16-byte gather instead of three dependent ones at random i (round 5: these gathers were
-                                  // 18 % of the fused logic pass, profiles/r05_logic_probes_ab.txt); built at flx_upload_envmap, values copied bit for bit
+    const float2 *aliasRec;       // {probTable[i], aliasTable[i] (int bits)}: the alias step of sample_env_alias is ONE 8-byte gather at the random index
+                                  // instead of two dependent ones (round 5: the light sample's gathers were 18 % of the fused logic pass,
+                                  // profiles/r05_logic_probes_ab.txt); built at flx_upload_envmap, values copied bit for bit
+    // everything next-event estimation computes for an importance-sampled texel is a function of the texel alone -- the direction of its centre (two
+    // sincos + normalize), its solid-angle pdf (a sine, a division), the radiance looked up in that direction (atan2, acos, four texels, the bilinear
+    // blend): {L.xyz, pdfW} {Li.xyz, 0} per texel, filled at flx_upload_envmap by a kernel that runs the very device functions the inline code ran
+    // (flx_shading.h: env_sample_compute), so the values are the same bit for bit.  Round 5: that code was 16 % of the fused logic pass.
+    const float4 *neeRec;
     int envW, envH;
 };
 

@@ -24,7 +24,11 @@ __device__ __forceinline__ f3 read_texture(const Scene &sc, f2 uv, int idx)
 }
 
 // reference: src/utils.cl:136-146
+#ifdef FLX_LAB_NOTEX                 // lab build only (RESULTS INVALID): no texture fetches
+__device__ __forceinline__ f3 mat_float3(const Scene &sc, f3 fallback, f2 uv, int idx) { return fallback; }
+#else
 __device__ __forceinline__ f3 mat_float3(const Scene &sc, f3 fallback, f2 uv, int idx) { return idx != -1 ? read_texture(sc, uv, idx) : fallback; }
+#endif
 __device__ __forceinline__ f3 mat_albedo(const Scene &sc, f3 fallback, f2 uv, int idx) { return pow3(mat_float3(sc, fallback, uv, idx), 2.2f); }
 
 // reference: src/utils.cl:149-182
@@ -97,10 +101,9 @@ __device__ __forceinline__ void sample_env_alias(const Scene &sc, float rnd, f3 
     float r = rnd * (float)width * (float)height;
     int i = (int)floorf(r);
     if (i > width * height - 1) i = width * height - 1;
-    const float4 rec = sc.aliasRec[i];                              // {prob[i], alias[i], pdf[i], pdf[alias[i]]} (flx_device.h)
-    const bool own = r - (float)i < rec.x;
-    int uvInd = own ? i : __float_as_int(rec.y);
-    float pdf_uv = own ? rec.z : rec.w;
+    const float2 rec = sc.aliasRec[i];                              // {prob[i], alias[i]} (flx_device.h)
+    int uvInd = (r - (float)i < rec.x) ? i : __float_as_int(rec.y);
+    float pdf_uv = sc.pdfTable[uvInd];
     int uInd = uvInd % width, vInd = uvInd / width;
     float u = ((float)uInd + 0.5f) / (float)width;
     float v = ((float)vInd + 0.5f) / (float)height;
@@ -109,6 +112,37 @@ __device__ __forceinline__ void sample_env_alias(const Scene &sc, float rnd, f3 
     float directPdfUV = pdf_uv * 1.0f;
     if (sinTh != 0.0f) *pdfW = directPdfUV / (2.0f * FLX_PI * FLX_PI * sinTh);
     else *pdfW = 0.0f;
+}
+
+// the alias step alone: which texel the random number picks (the first half of sample_env_alias)
+__device__ __forceinline__ int sample_env_index(const Scene &sc, float rnd)
+{
+    int width = sc.envW, height = sc.envH;
+    float r = rnd * (float)width * (float)height;
+    int i = (int)floorf(r);
+    if (i > width * height - 1) i = width * height - 1;
+    const float2 rec = sc.aliasRec[i];
+    return (r - (float)i < rec.x) ? i : __float_as_int(rec.y);
+}
+// what logic's next-event estimation derives from the sampled texel uvInd (src/wf_logic.cl:236-249 through src/env_map.cl:65-92 and :39-43): the
+// second half of sample_env_alias, the normalisation of the direction and the radiance lookup along it -- the operations of the inline code, in its order
+struct EnvSample { f3 L; float pdfW; f3 Li; };
+__device__ __forceinline__ EnvSample env_sample_compute(const Scene &sc, int uvInd)
+{
+    int width = sc.envW, height = sc.envH;
+    EnvSample e;
+    float pdf_uv = sc.pdfTable[uvInd];
+    int uInd = uvInd % width, vInd = uvInd / width;
+    float u = ((float)uInd + 0.5f) / (float)width;
+    float v = ((float)vInd + 0.5f) / (float)height;
+    f3 L = uv_to_direction(u, v);
+    float sinTh = sinf_(FLX_PI * v);
+    float directPdfUV = pdf_uv * 1.0f;
+    if (sinTh != 0.0f) e.pdfW = directPdfUV / (2.0f * FLX_PI * FLX_PI * sinTh);
+    else e.pdfW = 0.0f;
+    e.L = normalize(L);
+    e.Li = eval_env_dir(sc, e.L);
+    return e;
 }
 
 // reference: src/env_map.cl:95-107
@@ -121,6 +155,37 @@ __device__ __forceinline__ float env_map_pdf(const Scene &sc, f3 direction)
     int iu = (int)floorf(uv.x * (float)width); if (iu > width - 1) iu = width - 1;
     int iv = (int)floorf(uv.y * (float)height); if (iv > height - 1) iv = height - 1;
     return sc.pdfTable[iv * width + iu] / (FLX_2PI * FLX_PI * sinTh);
+}
+
+// ---- camera ray of a (re)generated path (reference: genRays, src/wf_raygen.cl:22-66): jittered pixel position, pinhole direction, thin-lens origin.
+// Shared by k_raygen (misc.hip) and the fused logic pass's in-kernel regeneration (logic.hip).  localIdx: the rank's local pixel (cursor + queue index).
+__device__ __forceinline__ void camera_ray(const Frame &fr, const flx_render_params &p, uint32_t localIdx, uint32_t *seedp, f3 *orig, f3 *dir)
+{
+    uint32_t seed = *seedp;
+    const uint32_t pixelIdx = localIdx * fr.nranks + fr.rank;
+    float x = (float)(pixelIdx % p.width);
+    float y = (float)(pixelIdx / p.width);
+    x += rand01(&seed);
+    y += rand01(&seed);
+    float NDCx = x / (float)p.width;
+    float NDCy = y / (float)p.height;
+    float SCRx = 2.0f * NDCx - 1.0f;
+    float SCRy = 2.0f * NDCy - 1.0f;
+    SCRx *= (float)p.width / (float)p.height;
+    const float scale = tanf_(0.5f * p.camera.fov * FLX_PI / 180.0f);
+    SCRx *= scale;
+    SCRy *= scale;
+    f3 rayOrig = V(p.camera.pos);
+    f3 rayTarget = rayOrig + V(p.camera.right) * SCRx + V(p.camera.up) * SCRy + V(p.camera.dir);
+    f3 rayDirection = normalize(rayTarget - rayOrig);
+    const f3 fp = V(p.camera.pos) + rayDirection * p.camera.focalDist;
+    const float sqrt_r = sqrtf(rand01(&seed));                 // uniformSampleDisk, src/utils.cl:75-80
+    const float th = FLX_2PI * rand01(&seed);
+    float sn, cs; sincosf_(th, &sn, &cs);
+    const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
+    rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
+    rayDirection = normalize(fp - rayOrig);
+    *seedp = seed; *orig = rayOrig; *dir = rayDirection;
 }
 
 } // namespace flxd

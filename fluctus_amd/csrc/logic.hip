@@ -66,7 +66,60 @@ struct LogicAux {
     uint32_t *blockOffsets;   // NUM_LISTS x numBlocks
     uint32_t numBlocks;
     uint32_t stride;          // elements between two lists in blockCounts / blockOffsets: numBlocks rounded up for the scan's uint4 accesses
+    // in-kernel regeneration (k_logic<FUSE, RAW>, LOGIC_REGEN): one status word per wave for the decoupled look-back over the terminating paths
+    unsigned long long *lookback;
+    uint32_t epoch;           // launch number: a status word counts only if it carries this launch's epoch (no reset between launches)
+    uint32_t regen;           // 1: terminating lanes are regenerated here (the genRays of this chain is not launched) | 0: off
+    uint32_t appendExt;       // regen: append the regenerated paths to the extension queue at extBase + rank (genRays' appendExt)
+    uint32_t *error;          // set when a look-back gives up (never observed; a hang would take the box down, a flag fails the test)
 };
+
+// ---- decoupled look-back over waves (Merrill & Garland 2016), for ONE running count: how many paths with a smaller id terminate in this pass = the
+// index genRays' queue would give the path = its pixel (src/wf_raygen.cl:25).  Status word: bits 0..25 value | 26..27 flag (1 the wave's own count,
+// 2 the inclusive prefix up to and including the wave) | 28..63 epoch.  Waves are dispatched in id order, a wave publishes its count before it
+// looks back and never waits for a later wave: no deadlock; the spin is bounded all the same.
+#define LB_VALUE(x) ((uint32_t)((x) & 0x3FFFFFFull))
+#define LB_FLAG(x) ((uint32_t)(((x) >> 26) & 3ull))
+#define LB_EPOCH(x) ((uint32_t)((x) >> 28))
+#define LB_PACK(e, f, v) (((unsigned long long)(e) << 28) | ((unsigned long long)(f) << 26) | (unsigned long long)(v))
+// sum of a value <= 127 over the ACTIVE lanes where `take` holds (ballots only see active lanes: right for the partial last wave too)
+__device__ __forceinline__ uint32_t wave_sum7(uint32_t v, bool take)
+{
+    uint32_t s = 0u;
+    #pragma unroll
+    for (int b = 0; b < 7; b++) s += (uint32_t)__popcll(__ballot(take && ((v >> b) & 1u))) << b;
+    return s;
+}
+// the calling lanes are lanes 0 .. win - 1 of the wave (a full wave, or the head of the last one); returns the exclusive prefix of this wave's count
+__device__ __forceinline__ uint32_t lookback_exclusive(const LogicAux &aux, uint32_t wave, uint32_t count)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t win = (uint32_t)__popcll(__ballot(true));
+    unsigned long long *st = aux.lookback;
+    if (lane == 0u) __hip_atomic_store(st + wave, LB_PACK(aux.epoch, wave == 0u ? 2u : 1u, count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0u) return 0u;
+    uint32_t sum = 0u;
+    long long j = (long long)wave - 1;                   // nearest predecessor not yet accounted for
+    for (uint32_t spins = 0;;) {
+        const long long idx = j - (long long)lane;
+        unsigned long long v = LB_PACK(aux.epoch, 2u, 0u);                     // below wave 0: prefix 0
+        if (idx >= 0) v = __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = LB_EPOCH(v) == aux.epoch && LB_FLAG(v) != 0u;
+        const uint64_t b2 = __ballot(ok && LB_FLAG(v) == 2u), bad = __ballot(!ok);
+        const uint32_t first2 = b2 ? (uint32_t)__ffsll((long long)b2) - 1u : win;            // nearest predecessor that already has its prefix
+        const uint64_t need = first2 >= 64u ? ~0ull : ((1ull << first2) | ((1ull << first2) - 1ull));
+        if (bad & need) {                                                       // someone nearer has not published yet
+            if (++spins > (1u << 22)) { if (lane == 0u) *aux.error = 1u; break; }
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        sum += wave_sum7(LB_VALUE(v), lane < first2);                           // the own counts (<= 64 each) of the waves in between ...
+        if (b2) { sum += (uint32_t)__shfl((int)LB_VALUE(v), (int)first2, 64); break; }   // ... on top of the nearest published prefix
+        j -= (long long)win;
+    }
+    if (lane == 0u) __hip_atomic_store(st + wave, LB_PACK(aux.epoch, 2u, sum + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return sum;
+}
 
 __device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
 {
@@ -97,7 +150,7 @@ __device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
 #define LOGIC_BOUNDS __launch_bounds__(LOGIC_BLOCK)
 #endif
 template <int FUSE, bool RAW = false>
-__global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, uint32_t firstIteration)
+__global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, Queues qs, uint32_t firstIteration)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
     uint32_t maxId = st.numTasks;
@@ -202,17 +255,30 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
         // Lane classes at the store phases:  T terminating (regenerated by the genRays that follows) | C1 continuing, BSDF inlined here |
         // C2 continuing, served by the material kernel that follows | C0 continuing, no queue (unknown BSDF type: the reference drops the path).
         constexpr bool FULL = LOGIC_FULL_STORES != 0 && RAW && FUSE != 0;
+        // ---- REGEN (aux.regen): a terminating lane is regenerated HERE instead of by the genRays kernel of the chain -- its new origin, direction,
+        // radiance + pixel and throughput + seed records ride on the full-line stores below, where genRays wrote four isolated 16-byte records per
+        // path (partial sectors again: 0.15-0.19 ms per iteration for 1.8 M paths).  The one thing genRays has that a lane here has not is its index
+        // in the raygen queue (= pixel, src/wf_raygen.cl:25): the number of terminating paths with a smaller id -- a decoupled look-back over the waves.
+        uint32_t regenRank = 0u, regenLocal = 0u;
+        const bool regen = FULL && aux.regen != 0u;
+        if (regen) {
+            const uint64_t tb = __ballot(terminate);
+            regenRank = lookback_exclusive(aux, gid >> 6, (uint32_t)__popcll(tb)) + mbcnt(tb);
+            regenLocal = (*fr.currPixelIdx + regenRank) % fr.localPixels;
+        }
         flx_material mat;
         bool backface = false, haveL = false, neeBlocked = false, inlined = false;
         f3 hitP = rawP, orig = mk3(0.0f), Lnee = mk3(0.0f), neeLi = mk3(0.0f);
         float hitT = rawT, neeLen = 0.0f, neePdf = 0.0f, neeCos = 0.0f, neePick = 0.0f;
         uint32_t ml = 0u;
         auto splat = [&]() {                                          // splat + regenerate, :163-177
+#ifndef FLX_LAB_LOGIC_NOSPLAT      // lab build only (RESULTS INVALID: no image): the pass without its 4 float atomics per terminating path
             if (len > 0u) {
                 float *px = fr.pixels + (size_t)pixIdx * 4;
                 unsafeAtomicAdd(px + 0, Ei.x); unsafeAtomicAdd(px + 1, Ei.y);
                 unsafeAtomicAdd(px + 2, Ei.z); unsafeAtomicAdd(px + 3, 1.0f);
             }
+#endif
         };
         if (terminate) {
             if (!FULL) {
@@ -268,11 +334,13 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
                     const float cosTh = fmaxf_(0.0f, dot(L, hitN));
                     const f3 envMapLi = mk3(directPdfW, cosTh, 0.5f) * p.envMapStrength;
 #else
-                    sample_env_alias(sc, rand01(&seed), &L, &directPdfW);
+                    // (sample_env_alias, normalize, eval_env_dir: precomputed per texel, flx_device.h neeRec -- the same values bit for bit)
+                    const int uvInd = sample_env_index(sc, rand01(&seed));
+                    const float4 n0 = sc.neeRec[2 * (size_t)uvInd], n1 = sc.neeRec[2 * (size_t)uvInd + 1];
+                    L = ld3(n0); directPdfW = n0.w;
                     const float lenL = 2.0f * p.worldRadius;
-                    L = normalize(L);
                     const float cosTh = fmaxf_(0.0f, dot(L, hitN));
-                    const f3 envMapLi = eval_env_dir(sc, L) * p.envMapStrength;
+                    const f3 envMapLi = ld3(n1) * p.envMapStrength;
 #endif
                     neeLen = lenL; neePdf = directPdfW; neeLi = envMapLi; neeCos = cosTh; neePick = envMapProb;
                     haveL = true; Lnee = L;
@@ -325,7 +393,11 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
             // continuing lane that sampled no light.
             float4 sho = mk4(orig, neeLen), shd = mk4(Lnee, neePdf), le = mk4(neeLi, neeCos);
             float pick = neePick;
+#ifdef FLX_LAB_LOGIC_NOOLD          // lab build only (RESULTS INVALID: exported shadow records of regenerated paths): the pass without the write-back loads
+            if (!haveL && !terminate) {
+#else
             if (!haveL) {
+#endif
                 sho = rd4(st.at(S_SHO, gid)); shd = rd4(st.at(S_SHD, gid));
                 if (!terminate) { le = rd4(st.at(S_LEMIT, gid)); pick = st.pickProb[gid]; } else pick = 1.0f;      // (T: genRays' lastLightPickProb)
                 Lold = ld3(shd);
@@ -338,7 +410,8 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
             wr4(st.at(S_SHD, gid), shd);
             wr4(st.at(S_LEMIT, gid), le);
             st.pickProb[gid] = pick;
-            wr4(st.at(S_EI, gid), mk4(Ei, eiw));
+            // (REGEN, T: genRays' Ei = 0 and the new pixel with the "no NEE sample since regeneration" flag; the splat below still has the old Ei)
+            wr4(st.at(S_EI, gid), (regen && terminate) ? mk4u(mk3(0.0f), FLX_FRESH | regenLocal) : mk4(Ei, eiw));
         }
 
         MatStep o;
@@ -380,13 +453,28 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
             const bool c1 = !terminate && inlined, c0 = !terminate && !inlined && ml == 0u;
             float4 lbs = mk4(o.bsdfNEE, o.bsdfPdfW), lt4 = mk4u(T, o.singular), or4 = mk4(o.orig, o.pdfW), dr4 = mk4u(o.newDir, len);
             if (!c1) {
+#ifdef FLX_LAB_LOGIC_NOOLD
+                if (c0) lt4 = rd4(st.at(S_LT, gid));
+#else
                 if (terminate || c0) lt4 = rd4(st.at(S_LT, gid));
+#endif
                 if (!terminate) { dr4 = rd4t(st.at(S_DIR, gid)); dr4.w = __uint_as_float(lenBits); }     // (this thread loaded the line at the top)
                 if (c0) { lbs = rd4(st.at(S_LBSDF, gid)); or4 = rd4t(st.at(S_ORIG, gid)); }
             }
+            float4 thr4 = mk4u(c1 ? o.newT : T, seed);
+            if (regen && terminate) {                                 // genRays for this lane (misc.hip: k_raygen), index in the raygen queue = regenRank
+                uint32_t sd = seed; f3 ro, rd;
+                camera_ray(fr, p, regenLocal, &sd, &ro, &rd);
+                or4 = mk4(ro, 1.0f);                                  // lastPdfW = 1
+                dr4 = mk4u(rd, FLX_FRESH | 0u);                       // pathLen = 0 + "no material kernel since regeneration"
+                thr4 = mk4u(mk3(1.0f), sd);
+                st.blocked[gid] = 1u;                                 // (lastLightPickProb = 1 went out with store phase A)
+                st.firstDiffuse[gid] = 0u;
+                if (aux.appendExt) qs.q[FLX_Q_EXTENSION][ext_len(qs) + regenRank] = gid;
+            }
             wr4(st.at(S_LBSDF, gid), lbs);
             wr4(st.at(S_LT, gid), lt4);
-            wr4(st.at(S_THR, gid), mk4u(c1 ? o.newT : T, seed));
+            wr4(st.at(S_THR, gid), thr4);
             wr4(st.at(S_ORIG, gid), or4);
             wr4(st.at(S_DIR, gid), dr4);
             if (terminate) splat();
@@ -539,25 +627,29 @@ uint32_t fused_queue_mask(int fuse)
 
 // fuse: 0 = the plain logic kernel | USE_DIFFUSE | USE_ALL  (diffuse + glossy was measured too: never the best of the three)
 void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
-                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId, int raw)
+                  uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId, int raw,
+                  unsigned long long *lookback, uint32_t epoch, int regen, int regenAppendExt, uint32_t *error)
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
-    LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks)};
+    LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks), lookback, epoch, (uint32_t)(raw && regen), (uint32_t)regenAppendExt, error};
     const dim3 g(blocks), b(LOGIC_BLOCK);
     switch (fuse) {
     case USE_DIFFUSE:
-        if (raw) hipLaunchKernelGGL((k_logic<USE_DIFFUSE, true>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
-        else hipLaunchKernelGGL((k_logic<USE_DIFFUSE, false>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        if (raw) hipLaunchKernelGGL((k_logic<USE_DIFFUSE, true>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
+        else hipLaunchKernelGGL((k_logic<USE_DIFFUSE, false>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
         break;
     case USE_ALL:
-        if (raw) hipLaunchKernelGGL((k_logic<USE_ALL, true>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
-        else hipLaunchKernelGGL((k_logic<USE_ALL, false>), g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration);
+        if (raw) hipLaunchKernelGGL((k_logic<USE_ALL, true>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
+        else hipLaunchKernelGGL((k_logic<USE_ALL, false>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
         break;
-    default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, (uint32_t)firstIteration); break;
+    default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration); break;
     }
     hipLaunchKernelGGL(k_queue_scan, dim3(NUM_LISTS), dim3(1024), 0, s, aux, qs.counters);
     hipLaunchKernelGGL(k_queue_scatter, g, b, 0, s, qs, aux, st.numTasks, fuse, (uint32_t)raygenFirst, (uint32_t)extByPathId);
 }
+// does this build regenerate terminating paths inside the fused RAW pass (LOGIC_FULL_STORES)?  (api.hip asks before it skips the genRays launch)
+int logic_can_regenerate() { return LOGIC_FULL_STORES != 0 ? 1 : 0; }
+uint32_t logic_lookback_words(uint32_t numTasks) { return (numTasks + 63u) / 64u; }
 
 } // namespace flxd

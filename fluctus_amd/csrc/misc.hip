@@ -60,29 +60,8 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Fram
         // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
         // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
         const uint32_t localIdx = (*fr.currPixelIdx + gd) % fr.localPixels;
-        const uint32_t pixelIdx = localIdx * fr.nranks + fr.rank;
-        float x = (float)(pixelIdx % p.width);
-        float y = (float)(pixelIdx / p.width);
-        x += rand01(&seed);
-        y += rand01(&seed);
-        float NDCx = x / (float)p.width;
-        float NDCy = y / (float)p.height;
-        float SCRx = 2.0f * NDCx - 1.0f;
-        float SCRy = 2.0f * NDCy - 1.0f;
-        SCRx *= (float)p.width / (float)p.height;
-        const float scale = tanf_(0.5f * p.camera.fov * FLX_PI / 180.0f);
-        SCRx *= scale;
-        SCRy *= scale;
-        f3 rayOrig = V(p.camera.pos);
-        f3 rayTarget = rayOrig + V(p.camera.right) * SCRx + V(p.camera.up) * SCRy + V(p.camera.dir);
-        f3 rayDirection = normalize(rayTarget - rayOrig);
-        const f3 fp = V(p.camera.pos) + rayDirection * p.camera.focalDist;
-        const float sqrt_r = sqrtf(rand01(&seed));                 // uniformSampleDisk, src/utils.cl:75-80
-        const float th = FLX_2PI * rand01(&seed);
-        float sn, cs; sincosf_(th, &sn, &cs);
-        const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
-        rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
-        rayDirection = normalize(fp - rayOrig);
+        f3 rayOrig, rayDirection;
+        camera_ray(fr, p, localIdx, &seed, &rayOrig, &rayDirection);
 
         // (temporal instead of non-temporal stores here: within the run-to-run spread, profiles/r03_raygen_temporal_ab.txt)
         wr4(st.at(S_ORIG, gid), mk4(rayOrig, 1.0f));                  // lastPdfW = 1
@@ -243,6 +222,19 @@ void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame
     uint32_t blocks = (st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK;
     if (blocks > 2048u) blocks = 2048u;
     hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, (uint32_t)appendExt);
+}
+// the per-texel table of next-event estimation (flx_device.h: Scene::neeRec)
+__global__ __launch_bounds__(MISC_BLOCK) void k_env_nee_table(Scene sc, float4 *out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * MISC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const EnvSample e = env_sample_compute(sc, (int)i);
+    out[2 * (size_t)i] = mk4(e.L, e.pdfW);
+    out[2 * (size_t)i + 1] = mk4(e.Li, 0.0f);
+}
+void launch_env_nee_table(hipStream_t s, const Scene &sc, float4 *out, uint32_t n)
+{
+    hipLaunchKernelGGL(k_env_nee_table, dim3((n + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, sc, out, n);
 }
 void launch_postprocess(hipStream_t s, const Frame &fr, const flx_render_params &p)
 {

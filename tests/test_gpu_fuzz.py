@@ -44,7 +44,7 @@ def _gen_sequence(rng):
             op = chain[pos % len(chain)]; pos += 1
         else:
             op = rng.choice(["logic", "raygen", "materials", "extend", "shadow", "clear", "counters", "finish", "params", "export", "qread",
-                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals"])
+                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals", "opt_regen"])
         if op == "logic":
             if logic_done:
                 continue
@@ -73,6 +73,8 @@ def _gen_sequence(rng):
             seq.append(("opt", "extend_tree", int(rng.choice([2, 4]))))
         elif op == "opt_fuseset":
             seq.append(("opt", "fuse_set", int(rng.choice([1, 31]))))
+        elif op == "opt_regen":                       # in-kernel regeneration of the fused RAW pass (logic.hip: REGEN) on / off
+            seq.append(("opt", "regen", int(rng.randint(0, 2))))
         elif op == "opt_overlap":
             seq.append(("opt", "overlap", int(rng.choice([0, 1, 2]))))
         elif op == "pixidx":
@@ -141,11 +143,11 @@ def test_call_sequence_fuzz(separate_queues, seed):
         hi = sg.view(np.uint32)[COL.HIT_I]
         exported_raw += int((((hi >> 30) & 3) == 1).sum())
 
-    def run(seq, fuse_set, ext_order, what, check_each=False):
+    def run(seq, fuse_set, ext_order, regen, what, check_each=False):
         nonlocal cursor
         g.set_option("fuse", 1); g.set_option("extend_tree", 4); g.set_option("refill_extend", 16 | (32 << 8)); g.set_option("overlap", 2)
         g.set_option("shadow_tree", 4); g.set_option("refill_shadow", 0)
-        g.set_option("fuse_set", fuse_set); g.set_option("ext_order", ext_order)
+        g.set_option("fuse_set", fuse_set); g.set_option("ext_order", ext_order); g.set_option("regen", regen)
         for c in (g, o):
             c.set_params(p)
         for k, op in enumerate(seq):
@@ -205,14 +207,15 @@ def test_call_sequence_fuzz(separate_queues, seed):
         # the extension-queue order of the fused pass: 0 the separate kernels' segments | 1 continuing paths by id | 2 merged with the regenerated ones
         # (the shipped default of the diffuse-only pass: the scatter writes the regenerated paths' entries and the deferred genRays must not append)
         ext_order = int(rng.choice([0, 1, 2]))
+        regen = int(rng.randint(0, 2))                 # the fused RAW pass regenerates its terminating paths itself (logic.hip: REGEN) | genRays does
         # every sequence starts from the oracle's current state, queues cleared
         for c in (g, o):
             c.clear_queues()
         common.sync(g, o)
         start, cursor0 = o.state_export(), cursor
-        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}) {seq}"
+        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}, regen {regen}) {seq}"
         try:
-            run(seq, fuse_set, ext_order, what)
+            run(seq, fuse_set, ext_order, regen, what)
         except AssertionError:
             # locate the call: same sequence from the same state, everything compared after every call
             for c in (g, o):
@@ -220,7 +223,7 @@ def test_call_sequence_fuzz(separate_queues, seed):
             cursor = cursor0
             for c in (g, o):
                 set_cursor(c)
-            run(seq, fuse_set, ext_order, what, check_each=True)
+            run(seq, fuse_set, ext_order, regen, what, check_each=True)
             raise
     assert exported_raw == 0, f"{exported_raw} RAW hit records were exported"
     phases = sorted({c[0] for c in covered})
