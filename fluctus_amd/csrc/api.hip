@@ -1325,6 +1325,15 @@ int flx_state_import(flx_ctx *c, const float *in)
     HIPCHK(c, e);
     return 0;
 }
+int flx_env_sample_table(flx_ctx *c, float *out)
+{
+    ENTER(c, CALL_QUIET);
+    NEED(c, out, "flx_env_sample_table: null");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->sc.neeRec, (size_t)c->sc.envW * c->sc.envH * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
 int flx_math_probe(flx_ctx *c, int fn, const float *a, const float *b, uint32_t n, uint32_t *out_bits)
 {
     ENTER(c, CALL_OBSERVE);

@@ -19,7 +19,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_clear_queues", "flx_get_counters_async", "flx_finish", "flx_pixel_index_update", "flx_pixel_index_reset",
            "flx_end_iteration_async", "flx_counter_totals", "flx_num_tasks", "flx_postprocess", "flx_read_pixels", "flx_set_partition", "flx_local_pixels",
            "flx_copy_pixels_to_device", "flx_stream", "flx_group_unique_id", "flx_group_init", "flx_group_init_local", "flx_gather", "flx_gather_local", "flx_group_destroy", "flx_group_info", "flx_profile_enable", "flx_profile_get", "flx_profile_reset",
-           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import", "flx_math_probe",
+           "flx_trace_stats_enable", "flx_trace_stats_get", "flx_trace_stats_get_ex", "flx_trace_stats_get_all", "flx_scene_info", "flx_trace_stats_reset", "flx_state_export", "flx_state_import", "flx_math_probe", "flx_env_sample_table",
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_get_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
@@ -189,6 +189,12 @@ class HipContext:
     def state_export(self):
         out = np.zeros((64, self.num_tasks), np.float32)
         self._chk(self.L.flx_state_export(self.h, _p(out)))
+        return out
+
+    def env_sample_table(self, w, h):
+        """(w * h, 8) float32: the per-texel light-sample table built at upload_envmap (test hook)."""
+        out = np.zeros((int(w) * int(h), 8), np.float32)
+        self._chk(self.L.flx_env_sample_table(self.h, _p(out)))
         return out
 
     def math_probe(self, fn, a, b):

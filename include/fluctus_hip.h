@@ -185,6 +185,9 @@ int flx_state_export(flx_ctx *ctx, float *out_64xN);
  * 2 tan, 3 atan2(a, b), 4 acos, 5 pow(a, b), 6 log, 7 exp, 8 asin, 9 atan, 10 fmin, 11 fmax, 12 a / b, 13 sqrt, 14 a * b, 15 a + b.
  * The oracle's orc_math_array is the CPU half: both sides must agree bit for bit, signed zeros included. */
 int flx_math_probe(flx_ctx *ctx, int fn, const float *a, const float *b, uint32_t n, uint32_t *out_bits);
+/* test hook: the per-texel light-sample table the library builds at flx_upload_envmap (8 floats per texel: {L.xyz, pdfW, Li.xyz, 0}).
+ * The oracle's orc_env_sample_table computes the same values inline, as the reference's logic kernel does per path (src/wf_logic.cl:236-249). */
+int flx_env_sample_table(flx_ctx *ctx, float *out_8_per_texel);
 int flx_state_import(flx_ctx *ctx, const float *in_64xN);
 int flx_queue_read(flx_ctx *ctx, int queue, uint32_t *out_N);
 int flx_queue_write(flx_ctx *ctx, int queue, const uint32_t *in, uint32_t n);

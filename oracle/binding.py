@@ -112,6 +112,14 @@ class OracleContext:
 
     def upload_envmap(self, e):
         self.L.orc_upload_envmap(self.h, _p(e.rgb), e.w, e.h, _p(e.prob), _p(e.alias), _p(e.pdf))
+        self._env_wh = (e.w, e.h)
+
+    def env_sample_table(self):
+        """(w * h, 8) float32: what next-event estimation derives from every texel of the uploaded map (orc_env_sample_table)."""
+        n = int(self._env_wh[0]) * int(self._env_wh[1])
+        out = np.zeros((n, 8), np.float32)
+        self.L.orc_env_sample_table(self.h, _p(out))
+        return out
 
     def set_params(self, p):
         self.params = p.copy()

@@ -1648,5 +1648,29 @@ void orc_math_array(int fn, const float *a, const float *b, uint32_t n, uint32_t
     for (uint32_t i = 0; i < n; i++) out[i] = f2u(orc_math(fn, a[i], b[i]));
 }
 uint32_t orc_hash(uint32_t s) { return hash_u32(s); }
+/* What `logic`'s next-event estimation derives from an importance-sampled texel, for EVERY texel of the uploaded environment map, with the calls and in the
+ * order of the kernel above (sampleEnvMapAlias' second half, normalize, evalEnvMapDir: src/wf_logic.cl:236-249, src/env_map.cl:65-92, :39-43): 8 floats per
+ * texel {L.xyz, pdfW, Li.xyz (before envMapStrength), 0}.  The device keeps exactly this as a table built at upload (flx_device.h: Scene::neeRec);
+ * tests/test_gpu_parity.py::test_env_sample_table_bit_identical compares the two bit for bit. */
+void orc_env_sample_table(orc_ctx *p, float *out)
+{
+    Ctx &c = CTX(p);
+    const int width = c.envW, height = c.envH;
+    for (int uvInd = 0; uvInd < width * height; uvInd++) {
+        float pdf_uv = c.pdfTable[uvInd];
+        int uInd = uvInd % width, vInd = uvInd / width;
+        float u = ((float)uInd + 0.5f) / (float)width;
+        float v = ((float)vInd + 0.5f) / (float)height;
+        f3 L = UVToDirection(u, v);
+        float sinTh = sinf_(FLX_PI * v);
+        float directPdfUV = pdf_uv * 1.0f;
+        float pdfW = 0.0f;
+        if (sinTh != 0.0f) pdfW = directPdfUV / (2.0f * FLX_PI * FLX_PI * sinTh);
+        L = normalize(L);
+        f3 Li = evalEnvMapDir(c, L);
+        float *o = out + (size_t)uvInd * 8;
+        o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = pdfW; o[4] = Li.x; o[5] = Li.y; o[6] = Li.z; o[7] = 0.0f;
+    }
+}
 
 } /* extern "C" */

@@ -559,6 +559,23 @@ def test_device_vs_reference_kernel_outputs(tag):
         assert not fails, f"step {k} {names[k]}: " + "; ".join(fails[:4])
 
 
+def test_env_sample_table_bit_identical():
+    """Round 5: the fused logic pass reads what next-event estimation derives from an importance-sampled texel -- direction of its centre, solid-angle pdf,
+    radiance looked up along it -- from a per-texel table the library builds at flx_upload_envmap.  EVERY entry of that table equals, bit for
+    bit, what the oracle computes inline with the reference kernel's calls in its order (orc_env_sample_table), for the reference's night.hdr and for a synthetic sky."""
+    import bench
+    from fluctus_amd.device import HipContext
+    from oracle.binding import OracleContext
+    for env in (bench.night_env(), host.synthetic_sky(64, 32)):
+        g, o = HipContext(256), OracleContext(256)
+        g.upload_envmap(env); o.upload_envmap(env)
+        tg, to = g.env_sample_table(env.w, env.h), o.env_sample_table()
+        assert tg.shape == to.shape == (env.w * env.h, 8)
+        bad = np.nonzero((tg.view(np.uint32) != to.view(np.uint32)).any(axis=1))[0]
+        assert bad.size == 0, f"{bad.size} of {tg.shape[0]} texels differ, first {bad[:4]}: {tg[bad[:2]]} vs {to[bad[:2]]}"
+        g.close()
+
+
 def test_arithmetic_contract_device_vs_oracle():
     """include/flx_math.h is the arithmetic contract both sides compile: every function of it (own sin / cos / tan / atan2 / acos / asin /
     atan / pow / log / exp, IEEE division and sqrt, fmin / fmax with their ordering of signed zeros) evaluated on the device
