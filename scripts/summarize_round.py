@@ -24,6 +24,9 @@ except Exception:
 # Steady state only: the first `settle_iterations` dispatches of every kernel are the transient from reset (iteration 0 traces nothing but
 # primary rays) and are dropped; what is averaged is the timed window + the extra untimed passes over the same steady state.
 skip = int(bench.get("settle_iterations", 0))
+# ... and (round 5) only the TIMED WINDOW's dispatches: bench.py runs extra untimed passes behind it (serial schedule, counting variants); the kernels of the
+# default chain launch once per iteration, so dispatches [skip, skip + steps x windows) of a kernel are the timed ones
+timed = int(bench.get("steps", 0)) * int((bench.get("windows") or {}).get("count", 1))
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     rows = collections.defaultdict(list)              # (key, counter) -> [(dispatch id, value)]
@@ -36,13 +39,15 @@ for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), rec
     for (key, cn), lst in rows.items():
         lst.sort()
         lst = lst[skip:] if len(lst) > 2 * skip else lst
+        if timed and len(lst) > timed:
+            lst = lst[:timed]
         a = acc[key][cn]
         a[0] += sum(v for _, v in lst); a[1] += len(lst)
 lines = []
 traffic = {}
 for k in sorted(acc):
     v = {c: a[0] / a[1] for c, a in acc[k].items()}
-    lines.append(f"== {k}   (averages per dispatch, {max(a[1] for a in acc[k].values())} steady-state dispatches; the first {skip} of the process dropped)")
+    lines.append(f"== {k}   (averages per dispatch, {max(a[1] for a in acc[k].values())} steady-state dispatches of the timed window; the first {skip} of the process and the extra untimed passes dropped)")
     for c in sorted(v):
         lines.append("   %-28s %.6g" % (c, v[c]))
     rd, r32, r64, r128 = (v.get("TCC_EA0_RDREQ_sum", 0), v.get("TCC_EA0_RDREQ_32B_sum", 0), v.get("TCC_EA0_RDREQ_64B_sum", 0), v.get("TCC_EA0_RDREQ_128B_sum", 0))

@@ -525,6 +525,38 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
         g.close()
 
 
+@pytest.mark.parametrize("workload", ["kitchen", "conference"])
+def test_in_kernel_regeneration_is_bit_identical_to_genrays(workload):
+    """Option `regen` (logic.hip: REGEN): the fused RAW pass regenerates its terminating paths itself -- their index in the raygen queue (= pixel,
+    src/wf_raygen.cl:25) comes from a decoupled look-back over the waves instead of from the queue scan -- and the genRays launch of the chain does nothing.
+    Two contexts free-run the workload at 1 M paths (16 384 waves: the look-back walks windows of 64 predecessors, which the 65-wave fuzz scenes never
+    make it do), one with genRays, one with the in-kernel regeneration; diffuse-inline pass with the merged extension queue on the kitchen, all-types
+    pass with genRays' own block on the conference scene: counters after every iteration, the whole state after 3 and 12, the framebuffers."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    ctx = []
+    for r in (0, 1):
+        g = HipContext(n)
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); g.set_option("regen", r); driver.reset_renderer(g)
+        ctx.append(g)
+    a, b = ctx
+    assert a.get_option("regen") == 0 and b.get_option("regen") == 1 and a.get_option("ext_order") == b.get_option("ext_order")
+    for it in range(12):
+        ca, cb = driver.benchmark_iteration(a, npix), driver.benchmark_iteration(b, npix)
+        assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
+        if it == 2:
+            fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+            assert not fails, "after 3 iterations: " + "; ".join(fails[:5])
+    fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+    assert not fails, "; ".join(fails[:5])
+    pa, pb = a.read_pixels(0), b.read_pixels(0)
+    assert np.array_equal(pa[:, 3], pb[:, 3]) and common.fb_close(pa, pb)
+    for g in ctx:
+        g.close()
+
+
 def test_raw_hit_records_call_patterns():
     """The persistent-wave extension kernel leaves RAW hit records; the host side of the boundary (api.hip: rawHits / KEEP_RAW / materialise)
     has to commit them the moment anything but the reference's own loop could observe a hit record -- and only then.  Call sequences that
