@@ -7,7 +7,7 @@
 Workload (BASELINE.json configs[1]): the kitchen-class scene at 1920x1080, 8 bounces, env-map MIS, separate
 material queues.  Country-Kitchen.obj is a missing blob in the reference checkout, so the scene is the
 deterministic procedural stand-in "kitchen-proc" (~0.5 M triangles, the real .mtl's material-type mix,
-SURVEY 8(d)) under the reference's own environment map (assets/env_maps/night.hdr, tests/golden/night_env.npz); SBVH built by the host library.  NUM_TASKS = 8 388 608 paths in flight per
+SURVEY 8(d)) under the reference's own environment map (assets/env_maps/night.hdr, tests/golden/night_env.npz); SBVH built by the host library.  NUM_TASKS = 16 777 216 paths in flight per
 GPU (the reference's `wfBufferSize` setting, re-tuned for this chip -- see the comment at NUM_TASKS).
 
 A step = one benchmark-style iteration of the reference's runBenchmark body (src/tracer.cpp:433-439):
@@ -36,7 +36,11 @@ WIDTH, HEIGHT, BOUNCES = 1920, 1080, 8
 # tail and seven dependent launches per iteration have their gaps, and 8 M paths amortise both (+5 % / +5 % / +8 %); 16 M loses again on the
 # scenes whose tree lives in the Infinity Cache (3.3 GB of path state stream through it per iteration).  8 M paths = 1.6 GB of state +
 # 0.3 GB of queues per GPU of 288 GB.
-NUM_TASKS = 1 << 23
+# Round 5, same box, 8 M / 12 M / 16 M / 24 M / 32 M (profiles/r05_num_tasks.txt): kitchen 6110-6260 / 6290 / 6340-6380 / 6400-6460 / 6470-6520, conference 5300 /
+# 5400-5470 / 5510-5540, courtyard-1440p 2435 -> 2500 at 16 M, egyptcat 5000 -> 5330: the fused pass no longer loses per path when the state outgrows the
+# Infinity Cache (its partial writes were what it paid for), so the fixed tails and launch gaps amortise further: 16 M paths (+2 ... +6 %) =
+# 3.4 GB of state + 0.6 GB of queues per GPU of 288 GB; beyond that the gain per doubling is ~1 %.
+NUM_TASKS = 1 << 24
 TARGET_TRIS, SCENE_SEED = 500000, 42
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
