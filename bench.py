@@ -144,7 +144,7 @@ def capture_key(args, ctx, p, C=1):
     return {"workload": args.workload, "width": int(p["width"]), "height": int(p["height"]), "max_bounces": int(p["maxBounces"]),
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
-            "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set"), "ext_order": ctx.get_option("ext_order"),
+            "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set_now"), "ext_order": ctx.get_option("ext_order"),
             "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"),
             # which BINARY ran: the shipped library or an A/B variant (FLX_HIP_LIB, e.g. a -DFLX_LAB build of the same sources), and its compile flags
             "library": os.path.basename(os.environ.get("FLX_HIP_LIB") or "libfluctus_hip.so"), "build_flags": " ".join(build.HIP_FLAGS),
@@ -631,7 +631,7 @@ def main():
                                     "separate material queues") if args.workload == "kitchen" else
                                    ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
-                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set_now") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
                        "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,

@@ -705,6 +705,11 @@ static int materialise(flx_ctx *c)
 // ... and a raygen queue that was EMPTY before this logic pass: the merged list is ranked from the scan offsets, which start at the raygen counter's old
 // value, while genRays with appendExt 0 would never fill the slots in front (flx_wf_reset leaves numTasks entries there without a clear: round 4's advisor)
 static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) ? 1 : c->extOrder; }
+// the BSDF set the fused pass inlines NOW: the scene's choice (flx_upload_scene / option "fuse_set") with separate material queues; with a single material
+// queue (WF_SINGLE_MAT_QUEUE: every BSDF type sits in the diffuse list) only a pass that inlines every type can serve it, so it is the all-types pass
+// whatever the scene's choice says -- round 5: egyptcat under the reference's benchmark protocol ran the separate logic + k_material<31> + k_materialise
+// (1.0 + 1.4 + 0.4 ms per 16 M paths) because its surfaces are mostly diffuse; the all-types pass takes their place: +16 % (profiles/r05_egyptcat_fuse.txt)
+static int fuseSetNow(const flx_ctx *c) { return c->params.wfSeparateQueues ? c->fuseSet : 31; }
 static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
 {
     // RAW hit records are committed by the fused pass itself when genRays follows in the same chain (logic.hip: k_logic<FUSE, RAW>); the plain
@@ -849,7 +854,7 @@ int flx_wf_logic(flx_ctx *c, int first)
     // src/tracer.cpp:257); otherwise, and with the option off, the kernel runs here and now.
     const uint32_t allMat = (1u << FLX_Q_DIFFUSE) | (1u << FLX_Q_GLOSSY) | (1u << FLX_Q_GGX_REFL) | (1u << FLX_Q_GGX_REFR) | (1u << FLX_Q_DELTA);
     // (with a single material queue every BSDF type sits in the diffuse list: only a pass that inlines them all can serve it)
-    const bool fusable = c->params.wfSeparateQueues || fused_queue_mask(c->fuseSet) == allMat;
+    const bool fusable = c->params.wfSeparateQueues || fused_queue_mask(fuseSetNow(c)) == allMat;      // (always: see fuseSetNow)
     if (c->fuse && c->matQueuesEmpty && fusable) { c->phase = PH_DEFER_LOGIC; c->pendFirst = first; }
     else { if (runLogic(c, first, 0, 0)) return 1; c->phase = PH_CHAIN; }
     return 0;
@@ -865,12 +870,13 @@ int flx_wf_materials(flx_ctx *c)
         ENTER(c, CALL_MATERIALS);
         NEED(c, c->haveParams && c->sc.bnodes, "set params and upload a scene first");
         HIPCHK(c, hipSetDevice(c->device));
-        const int order = extOrderFor(c, c->fuseSet, withRaygen);
-        if (runLogic(c, c->pendFirst, c->fuseSet, withRaygen)) return 1;
+        const int fuseNow = fuseSetNow(c);
+        const int order = extOrderFor(c, fuseNow, withRaygen);
+        if (runLogic(c, c->pendFirst, fuseNow, withRaygen)) return 1;
         if (withRaygen && runRaygen(c, order == 2 ? 0 : 1, c->regenDone)) return 1;
         c->regenDone = false;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
-        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(c->fuseSet), order); }
+        { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(fuseNow), order); }
         LAUNCHED(c);
         c->qs.extPend |= materialBits(c);
         if (c->eagerBump) flushExt(c);
@@ -1415,7 +1421,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(c->fuseSet)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(fuseSetNow(c))}, {"fuse_set_now", fuseSetNow(c)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;
