@@ -145,7 +145,7 @@ def capture_key(args, ctx, p, C=1):
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
             "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set_now"), "ext_order": ctx.get_option("ext_order"),
-            "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"),
+            "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"), "regroup": ctx.get_option("regroup"), "early_ext": ctx.get_option("early_ext"),
             # which BINARY ran: the shipped library or an A/B variant (FLX_HIP_LIB, e.g. a -DFLX_LAB build of the same sources), and its compile flags
             "library": os.path.basename(os.environ.get("FLX_HIP_LIB") or "libfluctus_hip.so"), "build_flags": " ".join(build.HIP_FLAGS),
             "source_hash": build.source_hash()}
@@ -199,6 +199,112 @@ def cpu_baseline(d, p, env, budget_s=12.0, force_kind=None):
             "sample": f"{what}; same scene/params, 65536 paths in flight, {iters} iterations after 16 warm-up, {dt:.1f} s"}
 
 
+def ref_gpu_baseline(ctx, d, p, args, settle):
+    """The reference's OWN wf_*.cl kernels on THIS GPU (untimed leg, rank 0 at N = 1; the product path is untouched): oracle/_ref/gfx950/fast/*.co =
+    /root/reference/src/wf_*.cl compiled unmodified for gfx950 with the reference's own build flags (-cl-fast-relaxed-math, src/clcontext.cpp:145) and
+    AMD's OpenCL built-in library (oracle/ref/Makefile, target gfx950), loaded by oracle/ref_gpu.py -- test infrastructure, imported here exactly like
+    cpu_baseline imports oracle.binding.
+      (a) `traversal`: the reference's traceExtension / traceShadow (src/wf_extrays.cl:5-36, src/wf_shadowrays.cl:6-38; NDRange = NUM_TASKS work-items,
+          src/clcontext.cpp:815-850) on the SAME extension / shadow queues and path state as the product's steady state at --num-tasks, each alone on the
+          machine, best of 3 -- beside the product's k_trace4r / k_shadow4 alone (serial schedule) on the same steady state;
+      (b) `whole_loop` (workloads without an environment map only: `logic` with USE_ENV_MAP samples an image and gfx950 has no image support): the
+          reference's complete runBenchmark iteration (src/tracer.cpp:433-439, one finishQueue per iteration) at its own wfBufferSize 2^20 and at
+          --num-tasks -> Mrays/s, beside the product at the same sizes."""
+    from fluctus_amd import device, driver
+    from oracle import ref_gpu
+    out = {"kind": "the reference's wf_*.cl kernels compiled for gfx950 (oracle/_ref/gfx950), same GPU", "flavour": "fast"}
+    if not ref_gpu.available("fast"):
+        out["error"] = "oracle/_ref/gfx950/fast not built (make -C oracle/ref gfx950 needs /root/reference: build container only)"
+        return out
+    n = int(args.num_tasks)
+    npix = int(p["width"]) * int(p["height"])
+    Q_EXT, Q_SH = 1, 2
+    # ---- (a) the two traversal kernels on the product's own steady-state queues
+    try:
+        ctx.set_option("overlap", 0)
+        ctx.wf_logic(False); ctx.wf_raygen(); ctx.wf_materials()
+        cnt = ctx.get_counters(); ctx.finish()
+        cnt = np.array(cnt, copy=True)
+        state = ctx.state_export()
+        qe, qs = ctx.queue_read(Q_EXT), ctx.queue_read(Q_SH)
+        r, backend = None, None
+        for backend in ("opencl", "hip"):
+            try:
+                r = ref_gpu.RefGpuContext(n, backend_name=backend, flavour="fast")
+                break
+            except Exception as e:                      # (e.g. CL_DEVICE_MAX_MEM_ALLOC_SIZE below the 4.3 GB state of 16 M paths)
+                out[f"{backend}_backend_error"] = str(e)[:200]
+        if r is None:
+            raise RuntimeError("no backend could hold the reference's path state")
+        r.upload_scene(d); r.set_params(p)
+        r.state_import(state); del state
+        r.queue_write(Q_EXT, qe); r.queue_write(Q_SH, qs); r.set_counters(cnt)
+        r.timed = True
+        te, ts = [], []
+        for _ in range(3):
+            r.wf_extend(); r.wf_shadow(); r.finish()
+            te.append(r.last_ms["traceExtension"]); ts.append(r.last_ms["traceShadow"])
+        r.close()
+        # the product's kernels alone on the same steady state (this iteration + 3 more, serial schedule, every launch event-timed)
+        ctx.profile_reset(); ctx.profile_enable(1)
+        ctx.wf_extend(); ctx.wf_shadow(); ctx.end_iteration_async()
+        for _ in range(3):
+            step_async(ctx)
+        ctx.finish(); ctx.profile_enable(0)
+        prof = ctx.profile_get()
+        he, hs = prof["extend"][0] / max(1, prof["extend"][1]), prof["shadow"][0] / max(1, prof["shadow"][1])
+        out["traversal"] = {"paths": n, "ext_rays": int(cnt[Q_EXT]), "shadow_rays": int(cnt[Q_SH]), "loader": backend,
+                            "ref_traceExtension_ms": min(te), "ref_traceShadow_ms": min(ts),
+                            "hip_extend_alone_ms": he, "hip_shadow_alone_ms": hs,
+                            "speedup_extend": min(te) / he if he else None, "speedup_shadow": min(ts) / hs if hs else None,
+                            "speedup_pair": (min(te) + min(ts)) / (he + hs) if (he + hs) else None}
+    except Exception as e:
+        out["traversal_error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        ctx.set_option("overlap", args.overlap)
+        ctx.counter_totals(reset=True)
+    # ---- (b) the reference's whole loop (no environment map: every kernel of it runs on gfx950)
+    if not int(p["useEnvMap"]):
+        loops = {}
+        for size in sorted({1 << 20, n}):
+            try:
+                r = ref_gpu.RefGpuContext(size, backend_name="hip", flavour="fast")      # (`logic` carries an image2d_t argument: module loader, null descriptor)
+                r.upload_scene(d); r.set_params(p)
+                driver.reset_renderer(r)
+                for _ in range(settle):
+                    driver.benchmark_iteration(r, npix)
+                rays, iters, t0 = 0, 0, time.perf_counter()
+                while iters < 8 or (time.perf_counter() - t0 < 3.0 and iters < 200):
+                    c_ = driver.benchmark_iteration(r, npix)
+                    rays += int(c_[Q_EXT]) + int(c_[Q_SH]); iters += 1
+                dt = time.perf_counter() - t0
+                r.close()
+                g = device.HipContext(size)
+                g.upload_scene(d); g.set_params(p)
+                driver.reset_renderer(g)
+                for _ in range(settle):
+                    step_async(g)
+                g.finish(); g.counter_totals(reset=True)
+                k = 20 if size > (1 << 22) else 60
+                g0 = time.perf_counter()
+                for _ in range(k):
+                    step_async(g)
+                g.finish()
+                gdt = time.perf_counter() - g0
+                tot = g.counter_totals(reset=True)
+                g.close()
+                loops[str(size)] = {"ref_Mrays_s": rays / dt / 1e6, "ref_ms_per_iteration": dt / iters * 1e3, "ref_iterations": iters,
+                                    "hip_Mrays_s": (float(tot[1]) + float(tot[2])) / gdt / 1e6, "hip_ms_per_iteration": gdt / k * 1e3,
+                                    "speedup": ((float(tot[1]) + float(tot[2])) / gdt) / (rays / dt) if rays else None}
+            except Exception as e:
+                loops[str(size)] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["whole_loop"] = loops
+    else:
+        out["whole_loop"] = None
+        out["whole_loop_note"] = "logic with USE_ENV_MAP samples an image2d_t (read_imagef); gfx950 has no image support, so the reference's whole loop cannot run on this device for an env-map workload"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +312,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--windows", type=int, default=5, help="back-to-back timed windows of --steps steps each; the headline is the MEDIAN window (all of them are in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-gpu-baseline", action="store_true", help="skip the untimed leg that runs the reference's own gfx950 kernels on this GPU (ref_gpu_baseline)")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--workload", default="kitchen", choices=sorted(WORKLOADS))
@@ -220,10 +327,13 @@ def main():
     ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
     ap.add_argument("--regen", type=int, default=-1, help="in-kernel regeneration of terminating paths by the fused logic pass (option regen): 0 off (genRays kernel), 1 on, -1 = library default")
+    ap.add_argument("--early-ext", type=int, default=-1, help="early start of the closest-hit kernel on the queue segment of the paths the fused pass inlined (option early_ext): 0 off, n = on with that launch's grid capped at n waves per CU, -1 = library default")
+    ap.add_argument("--regroup", type=int, default=-1, help="all-types fused pass with its material step sorted by BSDF type per block (option regroup): 0 / 1, -1 = what flx_upload_scene picks for the scene")
     ap.add_argument("--shadow-split", type=int, default=-1, help="tail splitting of the any-hit kernel: node-visit budget of the pass over the queue | budget of a second pass << 8; 0 = off, -1 = library default")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
     ap.add_argument("--node-layout", type=int, default=1)
     ap.add_argument("--eager-bump", type=int, default=0)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"), help="multi-GPU: weak = every rank runs --num-tasks paths of its own (default, the driver's SCALE runs); strong = the paths in flight are fixed: --num-tasks // world per rank (the framebuffer is fixed either way: north_star's tile split)")
     ap.add_argument("--kernel-timing", type=int, default=4, help="HIP-event timing inside the timed region: 0 none, 1 every kernel, 2 the trace kernels + span, 3 the extension kernel only, 4 the three kernels of the roofline block (extension, logic, shadow)")
     args = ap.parse_args()
 
@@ -236,6 +346,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    num_tasks_total = args.num_tasks
+    if args.scaling == "strong":
+        # total work fixed as N grows: the same paths in flight over the whole job, split evenly (whole waves per rank); the pixel partition is unchanged
+        args.num_tasks = max(64, (args.num_tasks // world) & ~63)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     # FLX_FORCE_DIST=1: take the RCCL code path (init, barrier, all-reduce, tile gather) even with one rank, so it can be
@@ -271,6 +385,9 @@ def main():
             c_.set_option("shadow_split", args.shadow_split)
         if args.regen >= 0:
             c_.set_option("regen", args.regen)
+        if args.early_ext >= 0:
+            c_.set_option("early_ext", args.early_ext)
+        c_.set_option("regroup", args.regroup)
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene
@@ -554,15 +671,40 @@ def main():
     simds = int(prop.multi_processor_count) * 4
     clock_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
     CYC, CYC_MIN = 4.0, 2.0
+    # Round 6: the cost of THIS kernel's instruction mix from its ISA (scripts/valu_roof.py -> profiles/valu_roof.json: opcode histogram of the hot loops of the
+    # shipped code object x the per-class issue cost the micro-benchmarks measured, two-pipe model), quoted only while the file's source_hash is that of the
+    # sources this library was built from.  Without it the line falls back to the round-5 bracket (4 = every instruction single-pipe, 2 = every one dual-pipe).
+    isa_roof = {}
+    try:
+        from fluctus_amd import build as _b
+        _vr = json.load(open(os.path.join(ROOT, "profiles", "valu_roof.json")))
+        if _vr.get("source_hash") == _b.source_hash() and not os.environ.get("FLX_HIP_LIB"):
+            isa_roof = _vr.get("kernels") or {}
+    except Exception:
+        isa_roof = {}
+    any_order = 1 if (int(p["useEnvMap"]) and not int(p["useAreaLight"])) else 0
+    k_ext = "k_trace4r<false, 0>" if ctx.get_option("refill_extend") else "k_extend4<false>"
+    k_sh = None if ctx.get_option("shadow_split") else (f"k_trace4r<true, {any_order}>" if ctx.get_option("refill_shadow") else f"k_shadow4<false, {any_order}>")
+    k_lg = (f"k_logic<{ctx.get_option('fuse_set_now')}, {'true' if ctx.get_option('refill_extend') else 'false'}>") if args.fuse else "k_logic<0, false>"
 
-    def valu_block(insts, lanes, secs):
+    def valu_block(insts, lanes, secs, kname=None):
         if not insts or not secs:
             return None
-        return {"instructions_per_launch": insts, "cycles_per_instruction": {"single_pipe": CYC, "dual_pipe": CYC_MIN}, "simds": simds, "clock_GHz": clock_hz / 1e9,
-                "issue_frac": insts * CYC / (simds * clock_hz * secs), "issue_frac_min": insts * CYC_MIN / (simds * clock_hz * secs),
+        avail = simds * clock_hz * secs
+        roof = isa_roof.get(kname) if kname else None
+        if roof and roof.get("cycles_per_instruction"):
+            cpi = float(roof["cycles_per_instruction"])
+            return {"instructions_per_launch": insts, "cycles_per_instruction": cpi, "cycles_per_instruction_range": roof.get("range"),
+                    "cycles_per_instruction_source": f"scripts/valu_roof.py: ISA of {kname} in the shipped code object (opcode histogram of its hot loops, trip-weighted) x measured per-class issue cost, two-pipe model; profiles/valu_roof.json",
+                    "simds": simds, "clock_GHz": clock_hz / 1e9, "issue_frac": insts * cpi / avail,
+                    "issue_frac_range": [insts * float(c_) / avail for c_ in (roof.get("range") or [cpi, cpi])],
+                    "lanes_per_instruction": lanes, "useful_lane_frac": (lanes / 64.0) if lanes else None}
+        return {"instructions_per_launch": insts, "cycles_per_instruction": {"single_pipe": CYC, "dual_pipe": CYC_MIN}, "cycles_per_instruction_source": "bracket (no profiles/valu_roof.json for these sources)",
+                "simds": simds, "clock_GHz": clock_hz / 1e9,
+                "issue_frac": insts * CYC / avail, "issue_frac_min": insts * CYC_MIN / avail,
                 "lanes_per_instruction": lanes, "useful_lane_frac": (lanes / 64.0) if lanes else None}
 
-    def pass_block(name, prof_keys, label, traversal):
+    def pass_block(name, prof_keys, label, traversal, kname=None):
         pb = passes.get(name) or {}
         ms, n = 0.0, 0
         for k_ in prof_keys:
@@ -571,14 +713,14 @@ def main():
         secs = (ms / n * 1e-3) if n else None
         by = pb.get("hbm_bytes_per_launch")
         hb = (by / secs / 1e9) if (by and secs) else None
-        vb = valu_block(pb.get("valu_instructions_per_launch"), pb.get("lanes_per_valu_instruction"), secs)
-        fr = {"hbm": (hb / HBM_PEAK_GBS) if hb else None, "valu-issue": (vb["issue_frac"] if traversal else vb["issue_frac_min"]) if vb else None}
+        vb = valu_block(pb.get("valu_instructions_per_launch"), pb.get("lanes_per_valu_instruction"), secs, kname)
+        fr = {"hbm": (hb / HBM_PEAK_GBS) if hb else None, "valu-issue": (vb["issue_frac"] if (traversal or "issue_frac_min" not in vb) else vb["issue_frac_min"]) if vb else None}
         best = max((v, k_) for k_, v in fr.items() if v is not None)[1] if any(v is not None for v in fr.values()) else None
         return {"kernel": label, "launch_ms": (secs * 1e3) if secs else None, "timed": ("timed region" if prof_keys[0] not in untimed else "extra untimed pass"),
                 "bound": best, "hbm": {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["hbm"], "traffic": by}, "valu": vb}
-    other = {"logic": pass_block("logic", ["logic_fused", "logic"], "logic (+ the inlined material step) + queue scan + scatter: k_logic<FUSE, RAW>, k_queue_scan, k_queue_scatter", False),
-             "shadow": pass_block("shadow", ["shadow"], "traceShadow (k_shadow4: 4-wide quantised tree, thread per ray)" if not ctx.get_option("shadow_split") else "traceShadow (k_shadow4s: tail-split)", True)}
-    ext_valu = valu_block(traffic_valu, traffic_lanes, launch_s if launch_s > 0 else None)
+    other = {"logic": pass_block("logic", ["logic_fused", "logic"], "logic (+ the inlined material step) + queue scan + scatter: k_logic<FUSE, RAW>, k_queue_scan, k_queue_scatter", False, k_lg),
+             "shadow": pass_block("shadow", ["shadow"], "traceShadow (k_shadow4: 4-wide quantised tree, thread per ray)" if not ctx.get_option("shadow_split") else "traceShadow (k_shadow4s: tail-split)", True, k_sh)}
+    ext_valu = valu_block(traffic_valu, traffic_lanes, launch_s if launch_s > 0 else None, k_ext if args.extend_tree == 4 else None)
     ext_hbm_frac = (ach / HBM_PEAK_GBS) if ach is not None else None
     ext_bound = "hbm"
     if ext_valu and (ext_hbm_frac is None or ext_valu["issue_frac"] > ext_hbm_frac):
@@ -588,7 +730,8 @@ def main():
                 # (roofline.valu: wave-instruction issue, the roof a divergent traversal on a cache-resident tree actually hits; MFMA has no work on this path)
                 "bound": ext_bound, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_hbm_frac, "traffic": traffic,
                 "valu": ext_valu, "other_kernels": other,
-                "frac_source": src, "traffic_capture_stale_keys": traffic_stale, "capture_key": key,
+                "frac_source": src, "traffic_source": (f"committed capture profiles/traffic_{args.workload}.json (rocprofv3 --pmc passes of scripts/profile_round.sh on this configuration and these kernel sources: capture_key), not measured in this run" if traffic else None),
+                "traffic_capture_stale_keys": traffic_stale, "capture_key": key,
                 "definition": "achieved = fabric-side bytes (memory-side L2 requests; Infinity-Cache hits included = upper bound of HBM proper) of the extension kernel per launch (profiles/traffic_<workload>.json: rocprofv3 --pmc request counters by size, separate passes, captured on THIS configuration and THESE kernel sources: capture_key) / the kernel's average launch time measured live with HIP events on its stream inside the timed region.  null when no capture matches (traffic_capture_stale_keys says why); frac_own = bytes the running kernel itself touches per ray, an upper bound.  launch_ms: as it runs in the timed region beside the concurrent shadow traversal; launch_ms_alone / frac_alone: same kernel, same steady state, serial schedule (untimed extra pass).",
                 "frac_alone": (ach * launch_s / alone_s / HBM_PEAK_GBS) if (ach is not None and alone_s > 0 and launch_s > 0) else None,
                 "launch_ms": launch_s * 1e3, "launch_ms_alone": alone_s * 1e3,
@@ -624,15 +767,15 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "windows": {"count": nwin, "headline": "median window", "Mrays_s": [float(x) for x in win_mrays], "ms_per_step": [float(e / args.steps * 1e3) for e in wins[:, 0]],
                         "spread_pct": float((win_mrays.max() - win_mrays.min()) / win_mrays[med] * 100.0)},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": ("real (reference asset egyptcat.obj + .mtl + texture)" if args.workload == "egyptcat" else
                                      "synthetic (procedural scene, deterministic); environment map: the reference's assets/env_maps/night.hdr" if int(p["useEnvMap"]) else "synthetic (procedural scene, deterministic)"),
             "config": {"workload": ("kitchen-proc (procedural stand-in for Country Kitchen OBJ), 1920x1080, 8 bounces, env-map MIS under night.hdr, "
                                     "separate material queues") if args.workload == "kitchen" else
                                    ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
-                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set_now") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
-                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
+                       "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "num_tasks_whole_job": args.num_tasks * world, "scaling_mode": ("weak: --num-tasks paths in flight per rank" if args.scaling == "weak" else f"strong: {num_tasks_total} paths in flight over the whole job, {args.num_tasks} per rank"), "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set_now") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
+                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"), "early_ext": ctx.get_option("early_ext"), "regroup": ctx.get_option("regroup"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},
@@ -648,6 +791,8 @@ def main():
             line["gather_native_nranks_seen"] = native_seen
             if native_err:
                 line["gather_native_error"] = native_err
+        if world == 1 and C == 1 and not args.no_ref_gpu_baseline:
+            line["ref_gpu_baseline"] = ref_gpu_baseline(ctx, d, p, args, settle)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
             if line["cpu_baseline"]["kind"] == "reference":      # the oracle port beside it (order-preserving appends instead of per-path atomics)

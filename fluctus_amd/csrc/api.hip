@@ -21,10 +21,10 @@ void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, c
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4_split(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *, uint32_t, uint4 *, uint32_t, uint4 *, uint32_t, int, int, uint32_t);
 uint32_t shadow_split_lists(); uint32_t shadow_split_count_words();
-void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
+void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *, uint32_t, uint32_t, int);
 void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int,
-                  unsigned long long *, uint32_t, int, int, uint32_t *);
+                  unsigned long long *, uint32_t, int, int, uint32_t *, int);
 void launch_env_nee_table(hipStream_t, const Scene &, float4 *, uint32_t);
 int logic_can_regenerate();
 uint32_t logic_lookback_words(uint32_t numTasks);
@@ -74,6 +74,17 @@ struct flx_ctx {
     int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
     int overlapOpt = -1;                        // option "overlap": -1 = the default (pickSchedule), else as set
     uint32_t *spill2 = nullptr;
+    // EARLY EXTENSION START (round 6, option "early_ext").  In the steady chain logic -> genRays -> materials -> extension the persistent closest-hit kernel used to
+    // start behind genRays and the material kernel of the non-inlined BSDF types -- two short kernels bound by isolated 16-byte stores (0.8 ms of a 4.9 ms kitchen
+    // step at 16 M paths, profiles/r05_kitchen_timeline.txt) -- although most of its rays exist the moment the fused pass ends: the continuing paths whose material
+    // step the pass inlined.  With early_ext on, the fused scatter lays the extension queue out in two segments (logic.hip, ext order 3: A = those paths, B = the
+    // regenerated paths + the paths of the other BSDF types; with the all-types pass the layout of order 1 already is [B | A]), flx_wf_extend launches the kernel
+    // on segment A on a third stream that waits for `logic` alone, and on segment B on the main stream behind genRays + the material kernel; the main stream then
+    // joins.  A ray's arithmetic does not depend on which launch traces it (tests: ..._bit_identical_to_thread_per_ray, the launch-chain tests); the queue holds the
+    // same set.  earlySeg is what the last fused chain laid out; it is used only if flx_wf_extend is the very next call (phase PH_CHAIN -> PH_CHAIN_EXT).
+    hipStream_t stream3 = nullptr; hipEvent_t evSegA = nullptr; uint32_t *spill3 = nullptr;
+    int earlyExt = 0;                           // option "early_ext": 0 off | n > 0: on, segment A's persistent grid capped at n waves per CU (>= 28: no cap)
+    struct { bool valid; uint32_t aBegin, aLen, bBegin, bLen; } earlySeg = {false, 0, 0, 0, 0};
     // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
     // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
@@ -81,6 +92,7 @@ struct flx_ctx {
     int fuse = 1;
     int extOrder = 0;                           // fused pass: extension queue lists the continuing paths 1 by path id | 2 merged with the regenerated ones by path id | 0 one segment per material queue; chosen at flx_upload_scene
     int fuseSet = 1;                            // BSDF types the fused pass inlines (logic.hip): 1 diffuse | 31 all six; chosen at flx_upload_scene
+    int regroup = 0, regroupAuto = 0, regroupOpt = -1;           // all-types fused pass with its material step sorted by BSDF type inside each block (logic.hip: LOGIC_REGROUP): the EFFECTIVE choice (flx_upload_scene) | option "regroup": -1 = that choice, 0 / 1 as set
     int pendFirst = 0;                          // the deferred flx_wf_logic's `first` (phases PH_DEFER_*)
     bool matQueuesEmpty = false;                // the five material counters are known to be zero (cleared, nothing appended since)
     bool raygenQueueEmpty = false;              // ... and the raygen counter (ext_order 2 ranks the regenerated paths from zero: extOrderFor)
@@ -98,7 +110,7 @@ struct flx_ctx {
     // in-kernel regeneration of the fused RAW pass (logic.hip: REGEN): look-back status words (one per wave, epoch-stamped: never reset), launch counter,
     // device error flag (a look-back that gave up), option "regen" (1: on where the pass allows it), and whether the LAST fused pass regenerated its
     // terminating paths itself -- then the genRays of the chain is not launched (flx_wf_materials)
-    unsigned long long *lookback = nullptr; uint32_t logicEpoch = 0; uint32_t *logicError = nullptr; int regenOpt = 0; bool regenDone = false;      // (off by default: profiles/r05_regen_ab.txt -- the look-back costs more than genRays)
+    unsigned long long *lookback = nullptr; uint32_t logicEpoch = 0; uint32_t *logicError = nullptr; int regenOpt = 0; bool regenDone = false; bool regenUsed = false;      // (off by default: profiles/r05_regen_ab.txt -- the look-back costs more than genRays)
     // trace aux
     uint32_t *spill = nullptr;
     unsigned long long *stats = nullptr;   // device, 16 counters
@@ -125,7 +137,7 @@ struct flx_ctx {
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as an entry point that could observe a hit record runs (transition(): commitRaw).
     bool rawHits = false;
-    bool cursorDirty[2] = {false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
+    bool cursorDirty[3] = {false, false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
@@ -180,7 +192,7 @@ struct ScopedTimer {
     ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream)
     {
         on = c->profile == 1 || (c->profile == 2 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW)) || (c->profile == 3 && k == FLX_K_EXTEND) ||
-             (c->profile == 4 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW || k == FLX_K_LOGIC || k == FLX_K_LOGIC_FUSED));
+             (c->profile == 4 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW || k == FLX_K_LOGIC || k == FLX_K_LOGIC_FUSED)) || (c->profile >= 2 && k == FLX_K_EXTEND_B);
         if (on) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); }
     }
     ~ScopedTimer() { if (on) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
@@ -308,6 +320,7 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pMain)) != hipSuccess) return fail("hipStreamCreate", e);
         if ((e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, pSecond)) != hipSuccess) return fail("hipStreamCreate", e);
     }
+    if ((e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSegA, hipEventDisableTiming)) != hipSuccess) return fail("hipStreamCreate(3)", e);
     if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
@@ -333,8 +346,9 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
     const size_t auxStride = logic_aux_stride(num_tasks);          // per list, padded for the scan kernel's uint4 accesses
     if (dalloc(c, c->fixedAllocs, &c->member, N) || dalloc(c, c->fixedAllocs, &c->blockCounts, (size_t)7 * auxStride) || dalloc(c, c->fixedAllocs, &c->blockOffsets, (size_t)7 * auxStride))
         return fail("hipMalloc(logic aux)", hipErrorOutOfMemory);
-    if (dalloc(c, c->fixedAllocs, &c->lookback, (size_t)logic_lookback_words(N)) || dalloc(c, c->fixedAllocs, &c->logicError, 1)) return fail("hipMalloc(lookback)", hipErrorOutOfMemory);
-    (void)hipMemsetAsync(c->lookback, 0, (size_t)logic_lookback_words(N) * 8, c->stream);
+    // (the look-back words of option "regen" and the continuation records of option "shadow_split" -- both off by default, together ~45 B per path -- are
+    //  allocated when the option is first switched on: optionBuffers)
+    if (dalloc(c, c->fixedAllocs, &c->logicError, 1)) return fail("hipMalloc(logic error flag)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->logicError, 0, 4, c->stream);
     (void)hipMemsetAsync(c->blockCounts, 0, (size_t)7 * auxStride * 4, c->stream);      // the pad behind each list's counts stays zero
     (void)hipMemsetAsync(c->blockOffsets, 0, (size_t)7 * auxStride * 4, c->stream);
@@ -344,12 +358,8 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
 #ifdef FLX_LAB_RSTATS
     flxd::g_lab_rstats = c->stats;
 #endif
-    // per sub-list: numTasks / 2 (first pass) and / 8 (second pass) records over all lists, whole waves
+    // per sub-list: numTasks / 2 (first pass) and / 8 (second pass) records over all lists, whole waves (allocated by optionBuffers)
     c->splitCapA = ((num_tasks / 2 / shadow_split_lists()) + 64u) & ~63u; c->splitCapB = ((num_tasks / 8 / shadow_split_lists()) + 64u) & ~63u;
-    if (dalloc(c, c->fixedAllocs, &c->splitCounts, shadow_split_count_words()) || dalloc(c, c->fixedAllocs, &c->splitRecA, (size_t)c->splitCapA * shadow_split_lists() * 4) ||
-        dalloc(c, c->fixedAllocs, &c->splitRecB, (size_t)c->splitCapB * shadow_split_lists() * 4))
-        return fail("hipMalloc(continuation records)", hipErrorOutOfMemory);
-    (void)hipMemsetAsync(c->splitCounts, 0, (size_t)shadow_split_count_words() * 4, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->totals, 8)) return fail("hipMalloc(totals)", hipErrorOutOfMemory);
     (void)hipMemsetAsync(c->totals, 0, 64, c->stream);
     if (dalloc(c, c->fixedAllocs, &c->fr.currPixelIdx, 1)) return fail("hipMalloc(cursor)", hipErrorOutOfMemory);
@@ -390,6 +400,8 @@ int flx_destroy(flx_ctx *c)
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
+    if (c->evSegA) (void)hipEventDestroy(c->evSegA);
     if (c->evPreExt) (void)hipEventDestroy(c->evPreExt);
     if (c->evShadow) (void)hipEventDestroy(c->evShadow);
     if (c->evPostLogic) (void)hipEventDestroy(c->evPostLogic);
@@ -413,6 +425,27 @@ static void pickSchedule(flx_ctx *c)
 {
     c->overlap = c->overlapOpt >= 0 ? c->overlapOpt : 2;
     c->refillShadow = c->refillShadowOpt >= 0 ? c->refillShadowOpt : 0;
+}
+
+// Device buffers of the two features that are off by default, allocated when the option is first switched on (round 5's advisor: at 16 M paths the
+// continuation records alone were 670 MB that the default configuration never touched) and kept until the context goes away.
+static int optionBuffers(flx_ctx *c, bool split, bool regen)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    if (split && !c->splitRecA) {
+        uint32_t *cnt = nullptr; uint4 *a = nullptr, *b = nullptr;
+        if (dalloc(c, c->fixedAllocs, &cnt, shadow_split_count_words()) || dalloc(c, c->fixedAllocs, &a, (size_t)c->splitCapA * shadow_split_lists() * 4) ||
+            dalloc(c, c->fixedAllocs, &b, (size_t)c->splitCapB * shadow_split_lists() * 4)) { c->err = "flx_set_option(shadow_split): out of device memory for the continuation records"; return 1; }
+        HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)shadow_split_count_words() * 4, c->stream));
+        c->splitCounts = cnt; c->splitRecA = a; c->splitRecB = b;
+    }
+    if (regen && !c->lookback) {
+        unsigned long long *lb = nullptr;
+        if (dalloc(c, c->fixedAllocs, &lb, (size_t)logic_lookback_words(c->numTasks))) { c->err = "flx_set_option(regen): out of device memory for the look-back words"; return 1; }
+        HIPCHK(c, hipMemsetAsync(lb, 0, (size_t)logic_lookback_words(c->numTasks) * 8, c->stream));
+        c->lookback = lb;
+    }
+    return 0;
 }
 
 // ---- scene upload: reference wire arrays -> traversal layout -------------------------------
@@ -448,6 +481,11 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         // all): courtyard (65 % diffuse) 2158 -> 2258 and 2221 -> 2274 Mrays/s at 1440p, 2088 -> 2167 and 2189 -> 2200 at 2160p -- a third of
         // its paths took the second trip -- kitchen (96 %) 5297 -> 5152 and 5485 -> 5198.  Hence all types below 3/4 diffuse (round 2: 1/2).
         c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.75 * areaAll) ? 31 : 1;
+        // ... and whether the all-types pass sorts its material step by BSDF type inside each block (logic.hip: LOGIC_REGROUP, k_logic<31, true, true>: 119 VGPRs
+        // against 92).  Same box, 16 M paths (profiles/r05_regroup_ab.txt, r06_regroup_ab.txt): courtyard (65 % diffuse) step +3.8 %, egyptcat (single material queue,
+        // mostly diffuse) +3.4 %, conference (13 % diffuse, three types of similar weight) -0.5 %: on where ONE type holds at least half of the surface area.
+        c->regroupAuto = (areaAll > 0.0 && areaDiffuse >= 0.5 * areaAll) ? 1 : 0;
+        c->regroup = c->regroupOpt >= 0 ? c->regroupOpt : c->regroupAuto;
         // ... and the order in which the fused pass lists the continuing paths in the extension queue (logic.hip: k_queue_scatter): one
         // segment per material queue, as the separate kernels append them, or all of them by path id.  Same-box A/B, Mrays/s segments ->
         // path id: conference 4318 -> 4446 (+3 %: three BSDF types of similar weight, the segments cut the id order into thirds),
@@ -577,6 +615,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     // so a failed upload leaves the context on its old scene instead of on dangling pointers.
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     std::vector<void *> fresh, freshSpill;
     auto bail = [&]() { freeAll(fresh); freeAll(freshSpill); return 1; };
     BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX; flxw::WNode *dW; float4 *dL;
@@ -584,10 +623,10 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         dalloc(c, fresh, &dTri, ntris) || dalloc(c, fresh, &dM, nmat) || dalloc(c, fresh, &dD, ntex) || dalloc(c, fresh, &dX, texbytes + 4) ||
         dalloc(c, fresh, &dW, wide.nodes.size()) || dalloc(c, fresh, &dL, wide.leafdata.size() + 4))
         return bail();
-    uint32_t *sp1 = c->spill, *sp2 = c->spill2;
+    uint32_t *sp1 = c->spill, *sp2 = c->spill2, *sp3 = c->spill3;
     const size_t lanes = ((size_t)c->numTasks + 255) / 256 * 256 + 1024;
     const bool newSpill = spillLevels > c->spillLevels || !c->spill;
-    if (newSpill && (dalloc(c, freshSpill, &sp1, lanes * spillLevels) || dalloc(c, freshSpill, &sp2, lanes * spillLevels))) return bail();
+    if (newSpill && (dalloc(c, freshSpill, &sp1, lanes * spillLevels) || dalloc(c, freshSpill, &sp2, lanes * spillLevels) || dalloc(c, freshSpill, &sp3, lanes * spillLevels))) return bail();
 #define UPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(); } } while (0)
     UPCHK(hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
     UPCHK(hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
@@ -601,7 +640,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
 #undef UPCHK
     freeAll(c->sceneAllocs);
     c->sceneAllocs.swap(fresh);
-    if (newSpill) { freeAll(c->spillAllocs); c->spillAllocs.swap(freshSpill); c->spill = sp1; c->spill2 = sp2; c->spillLevels = spillLevels; }
+    if (newSpill) { freeAll(c->spillAllocs); c->spillAllocs.swap(freshSpill); c->spill = sp1; c->spill2 = sp2; c->spill3 = sp3; c->spillLevels = spillLevels; }
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
     c->sc.wnodes = dW; c->sc.wleaf = dL; c->sc.wrootRef = wide.rootRef;
@@ -629,7 +668,6 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
     std::vector<float4> rgba(n);
     for (size_t i = 0; i < n; i++) rgba[i] = make_float4(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2], 1.0f);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    freeAll(c->envAllocs);
     // the probability and alias tables of the reference (src/envmap.cpp:31-114) merged into one record per texel (flx_device.h: aliasRec); the pdf table
     // stays as it is (env_map_pdf, and the per-texel NEE table below is built from it).  An alias outside the table (a malformed upload) is clamped like the kernel's own index clamp.
     std::vector<float2> rec(n);
@@ -638,16 +676,24 @@ int flx_upload_envmap(flx_ctx *c, const float *rgb, int w, int h, const float *p
         float af; memcpy(&af, &a, 4);
         rec[i] = make_float2(prob[i], af);
     }
-    float4 *dR; float2 *dRec; float *dF;
-    if (dalloc(c, c->envAllocs, &dR, n) || dalloc(c, c->envAllocs, &dRec, n) || dalloc(c, c->envAllocs, &dF, n)) return 1;
-    HIPCHK(c, hipMemcpy(dR, rgba.data(), n * 16, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dRec, rec.data(), n * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(dF, pdf, n * 4, hipMemcpyHostToDevice));
-    c->sc.envRGBA = dR; c->sc.aliasRec = dRec; c->sc.pdfTable = dF; c->sc.envW = w; c->sc.envH = h;
-    float4 *dNee; if (dalloc(c, c->envAllocs, &dNee, 2 * n)) return 1;
-    launch_env_nee_table(c->stream, c->sc, dNee, (uint32_t)n); HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->sc.neeRec = dNee;
+    // The new map is allocated and filled first; the previous one is released and c->sc switched only when every allocation, copy and the table
+    // kernel have succeeded, so a failed upload leaves the context on its old map instead of on dangling pointers (round 5's advisor).
+    std::vector<void *> fresh;
+    float4 *dR; float2 *dRec; float *dF; float4 *dNee;
+    auto bail = [&]() { freeAll(fresh); return 1; };
+    if (dalloc(c, fresh, &dR, n) || dalloc(c, fresh, &dRec, n) || dalloc(c, fresh, &dF, n) || dalloc(c, fresh, &dNee, 2 * n)) return bail();
+#define UPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(); } } while (0)
+    UPCHK(hipMemcpy(dR, rgba.data(), n * 16, hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dRec, rec.data(), n * 8, hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(dF, pdf, n * 4, hipMemcpyHostToDevice));
+    Scene tmp = c->sc;
+    tmp.envRGBA = dR; tmp.aliasRec = dRec; tmp.pdfTable = dF; tmp.envW = w; tmp.envH = h;
+    launch_env_nee_table(c->stream, tmp, dNee, (uint32_t)n); UPCHK(hipGetLastError());
+    UPCHK(hipStreamSynchronize(c->stream));
+#undef UPCHK
+    freeAll(c->envAllocs);
+    c->envAllocs.swap(fresh);
+    c->sc.envRGBA = dR; c->sc.aliasRec = dRec; c->sc.pdfTable = dF; c->sc.envW = w; c->sc.envH = h; c->sc.neeRec = dNee;
     return 0;
 }
 
@@ -704,7 +750,15 @@ static int materialise(flx_ctx *c)
 // (continuing paths by id, genRays appends its own block whenever it is called) otherwise
 // ... and a raygen queue that was EMPTY before this logic pass: the merged list is ranked from the scan offsets, which start at the raygen counter's old
 // value, while genRays with appendExt 0 would never fill the slots in front (flx_wf_reset leaves numTasks entries there without a clear: round 4's advisor)
-static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) ? 1 : c->extOrder; }
+static bool earlyExtPossible(const flx_ctx *c) { return c->earlyExt > 0 && c->overlap == 2 && c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn; }
+static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst)
+{
+    if (!fused) return 0;
+    if (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) return 1;
+    // order 3 = order 2 in two segments (EARLY EXTENSION START); only worth it when some BSDF type is NOT inlined (else order 1's [regenerated | continuing] is the split)
+    if (c->extOrder == 2 && earlyExtPossible(c)) return 3;
+    return c->extOrder;
+}
 // the BSDF set the fused pass inlines NOW: the scene's choice (flx_upload_scene / option "fuse_set") with separate material queues; with a single material
 // queue (WF_SINGLE_MAT_QUEUE: every BSDF type sits in the diffuse list) only a pass that inlines every type can serve it, so it is the all-types pass
 // whatever the scene's choice says -- round 5: egyptcat under the reference's benchmark protocol ran the separate logic + k_material<31> + k_materialise
@@ -716,6 +770,7 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     // kernel and a chain without genRays get them committed first
     // ... and only when the pass covers EVERY path: with `first` set, logic stops at min(numTasks, pixels) (src/wf_logic.cl:45-48) and the paths
     // beyond would keep their RAW records (found by tests/test_gpu_fuzz.py, round 4)
+    c->earlySeg.valid = false;
     const int raw = (c->rawHits && fused != 0 && raygenFirst && !first) ? 1 : 0;
     if (!raw && materialise(c)) return 1;
     c->rawHits = false;
@@ -726,11 +781,13 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     // REGEN: the RAW pass regenerates its terminating paths itself when their index in the raygen queue is their rank among the terminating paths,
     // i.e. when the raygen queue was empty before this pass (as for ext_order 2); the genRays call of the chain then launches nothing (flx_wf_materials)
     const int order = extOrderFor(c, fused, raygenFirst);
-    const int regen = (raw && c->regenOpt && logic_can_regenerate() && c->raygenQueueEmpty && c->fr.localPixels > 0) ? 1 : 0;
+    // (the look-back's status word carries the running prefix in 26 bits, logic.hip LB_VALUE: beyond 2^26 paths the genRays kernel does the job)
+    const int regen = (raw && c->regenOpt && c->lookback && logic_can_regenerate() && c->raygenQueueEmpty && c->fr.localPixels > 0 && c->numTasks <= (1u << 26)) ? 1 : 0;
     c->regenDone = regen != 0;
+    if (regen) c->regenUsed = true;
     if (++c->logicEpoch == 0u) c->logicEpoch = 1u;     // (epoch 0 = the zero-filled words of a fresh context)
     { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, order, raw,
-                                                                                c->lookback, c->logicEpoch, regen, order == 2 ? 0 : 1, c->logicError); }
+                                                                                c->lookback, c->logicEpoch, regen, (order == 2 || order == 3) ? 0 : 1, c->logicError, c->regroup); }
     LAUNCHED(c);
     c->matQueuesEmpty = false; c->raygenQueueEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -771,12 +828,29 @@ int flx_wf_extend(flx_ctx *c)
     // packet in front of the extension kernel)
     if (c->overlap && !(c->overlap == 2 && chainIntact)) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
+    if (chainIntact && c->earlySeg.valid && earlyExtPossible(c)) {
+        // EARLY EXTENSION START (flx_ctx::earlyExt): segment A on the third stream, behind `logic` alone; segment B here, behind genRays + the material kernel; join
+        c->earlySeg.valid = false;
+        uint32_t *curA = c->qs.cursors, *curB = c->qs.cursors + 16 * FLX_CURSOR_STRIDE;
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->evPostLogic, 0));
+        if (c->cursorDirty[0]) HIPCHK(c, hipMemsetAsync(curA, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream3));
+        { ScopedTimer t(c, FLX_K_EXTEND, c->stream3);
+          launch_extend4r(c->stream3, c->st, c->qs, c->sc, c->params, c->spill3, (uint32_t)c->numCUs, c->refillExt, curA, c->earlySeg.aBegin, c->earlySeg.aLen, c->earlyExt); }
+        HIPCHK(c, hipEventRecord(c->evSegA, c->stream3));
+        if (c->cursorDirty[2]) HIPCHK(c, hipMemsetAsync(curB, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream));
+        { ScopedTimer t(c, FLX_K_EXTEND_B);
+          launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, curB, c->earlySeg.bBegin, c->earlySeg.bLen, 0); }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evSegA, 0));
+        c->cursorDirty[0] = c->cursorDirty[2] = true; c->rawHits = true;
+        LAUNCHED(c);
+        return 0;
+    }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) {
             uint32_t *cur = c->qs.cursors;
             if (c->cursorDirty[0]) HIPCHK(c, hipMemsetAsync(cur, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream));      // (no k_end_iteration since the last launch)
-            launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, cur);
+            launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, cur, 0u, 0u, 0);
             c->cursorDirty[0] = true; c->rawHits = true;
         }
         else if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
@@ -873,8 +947,13 @@ int flx_wf_materials(flx_ctx *c)
         const int fuseNow = fuseSetNow(c);
         const int order = extOrderFor(c, fuseNow, withRaygen);
         if (runLogic(c, c->pendFirst, fuseNow, withRaygen)) return 1;
-        if (withRaygen && runRaygen(c, order == 2 ? 0 : 1, c->regenDone)) return 1;
+        if (withRaygen && runRaygen(c, (order == 2 || order == 3) ? 0 : 1, c->regenDone)) return 1;
         c->regenDone = false;
+        {   // which two segments the extension queue now consists of (EARLY EXTENSION START), as queue-counter masks
+            const uint32_t mats = materialBits(c), inl = fused_queue_mask(fuseNow) & mats, rg = 1u << FLX_Q_RAYGEN;
+            if (withRaygen && order == 3) c->earlySeg = {true, 0u, inl, inl, rg | (mats & ~inl)};                     // [A: inlined | B: regenerated + the other types]
+            else if (withRaygen && order == 1 && inl == mats && earlyExtPossible(c)) c->earlySeg = {true, rg, mats, 0u, rg};   // [B: regenerated (genRays appended them) | A: every continuing path]
+        }
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
         { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(fuseNow), order); }
         LAUNCHED(c);
@@ -920,9 +999,9 @@ int flx_clear_queues(flx_ctx *c)
     c->qs.extPend = 0; c->matQueuesEmpty = true; c->raygenQueueEmpty = true;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
-    if (c->cursorDirty[0] || c->cursorDirty[1]) {       // the block cursors of the persistent traversal kernels go with the counters
+    if (c->cursorDirty[0] || c->cursorDirty[1] || c->cursorDirty[2]) {       // the block cursors of the persistent traversal kernels go with the counters
         HIPCHK(c, hipMemsetAsync(c->qs.cursors, 0, 4 * FLX_NUM_BLOCK_CURSORS * FLX_CURSOR_STRIDE, c->stream));
-        c->cursorDirty[0] = c->cursorDirty[1] = false;
+        c->cursorDirty[0] = c->cursorDirty[1] = c->cursorDirty[2] = false;
     }
     return 0;
 }
@@ -945,9 +1024,14 @@ int flx_finish(flx_ctx *c)
     ENTER(c, CALL_QUIET);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->logicEpoch) {                                 // a look-back of the fused pass that gave up (logic.hip): fail loudly, never silently wrong pixels
+    if (c->regenUsed) {                                  // a look-back of the fused pass that gave up (logic.hip): fail loudly, never silently wrong pixels
+        // (only when a pass with in-kernel regeneration ran since the last check: the default configuration pays no read-back here)
         uint32_t e = 0; HIPCHK(c, hipMemcpy(&e, c->logicError, 4, hipMemcpyDeviceToHost));
-        if (e) { c->err = "k_logic: the in-kernel regeneration's look-back timed out"; return 1; }
+        c->regenUsed = false;
+        if (e) {                                         // reported ONCE: the flag is cleared, the regenerated paths of that pass are wrong -- the caller resets the renderer
+            HIPCHK(c, hipMemset(c->logicError, 0, 4));
+            c->err = "k_logic: the in-kernel regeneration's look-back timed out (paths regenerated by that pass are invalid: reset the renderer)"; return 1;
+        }
     }
     for (auto &p : c->pending) memcpy(p.user, &c->pinned[p.slot], 32);
     c->pending.clear();
@@ -986,7 +1070,7 @@ int flx_end_iteration_async(flx_ctx *c)
 {
     READY(c, CALL_NEUTRAL);
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend, c->qs.cursors);
-    c->cursorDirty[0] = c->cursorDirty[1] = false;      // (k_end_iteration zeroes the block cursors with the counters)
+    c->cursorDirty[0] = c->cursorDirty[1] = c->cursorDirty[2] = false;      // (k_end_iteration zeroes the block cursors with the counters)
     c->qs.extPend = 0;
     c->matQueuesEmpty = true; c->raygenQueueEmpty = true;      // it clears the queue counters
     LAUNCHED(c);
@@ -1390,7 +1474,9 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "xcd_remap") == 0) { c->xcdRemap = value; return 0; }
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
     if (name && strcmp(name, "ext_order") == 0 && value >= 0 && value <= 2) { c->extOrder = value; return 0; }
-    if (name && strcmp(name, "regen") == 0 && (value == 0 || value == 1)) { c->regenOpt = value; return 0; }
+    if (name && strcmp(name, "regen") == 0 && (value == 0 || value == 1)) { if (value && optionBuffers(c, false, true)) return 1; c->regenOpt = value; return 0; }
+    if (name && strcmp(name, "early_ext") == 0 && value >= 0 && value <= 64) { ENTER(c, CALL_OBSERVE); c->earlyExt = value; return 0; }
+    if (name && strcmp(name, "regroup") == 0 && value >= -1 && value <= 1) { c->regroupOpt = value; c->regroup = value >= 0 ? value : c->regroupAuto; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { ENTER(c, CALL_OBSERVE); c->overlapOpt = value; pickSchedule(c); return 0; }
     if (name && strcmp(name, "shadow_tree") == 0 && (value == 2 || value == 4)) { ENTER(c, CALL_OBSERVE); c->shadowTree = value; return 0; }
@@ -1403,7 +1489,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "refill_extend") == 0 && refill_value_ok(value)) { ENTER(c, CALL_OBSERVE); c->refillExt = value; return 0; }
     if (name && strcmp(name, "refill_shadow") == 0 && (value == -1 || refill_value_ok(value))) { ENTER(c, CALL_OBSERVE); c->refillShadowOpt = value; pickSchedule(c); return 0; }
     if (name && (strcmp(name, "refill_extend") == 0 || strcmp(name, "refill_shadow") == 0)) { c->err = "flx_set_option: refill value must be 0 or refillMin (1..64) | waitMax (0..64) << 8"; return 1; }
-    if (name && strcmp(name, "shadow_split") == 0 && value >= 0 && (value & 0xFF) <= 255 && (value >> 8) <= 255 && ((value & 0xFF) > 0 || value == 0)) { ENTER(c, CALL_OBSERVE); c->shadowSplit = value; return 0; }
+    if (name && strcmp(name, "shadow_split") == 0 && value >= 0 && (value & 0xFF) <= 255 && (value >> 8) <= 255 && ((value & 0xFF) > 0 || value == 0)) { ENTER(c, CALL_OBSERVE); if (value && optionBuffers(c, true, false)) return 1; c->shadowSplit = value; return 0; }
     if (name && strcmp(name, "shadow_split_limit") == 0 && value >= 0) { ENTER(c, CALL_OBSERVE); c->splitLimit = (uint32_t)value; return 0; }
     if (name && strcmp(name, "eager_bump") == 0 && (value == 0 || value == 1)) { c->eagerBump = value; return 0; }
     if (name && strcmp(name, "node_layout") == 0 && (value == 0 || value == 1)) { c->nodeLayout = value; return 0; }
@@ -1421,7 +1507,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(fuseSetNow(c))}, {"fuse_set_now", fuseSetNow(c)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"regroup", c->regroup}, {"early_ext", c->earlyExt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(fuseSetNow(c))}, {"fuse_set_now", fuseSetNow(c)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;

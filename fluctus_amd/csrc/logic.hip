@@ -59,6 +59,24 @@ __host__ __device__ constexpr bool fuse_inlines_list(int fuse, uint32_t ml)     
 #ifndef LOGIC_FULL_STORES
 #define LOGIC_FULL_STORES 1
 #endif
+// LOGIC_REGROUP (round 5): the all-types pass runs the material step BSDF-UNIFORM.  Inlining every BSDF type means a wave runs every type's code one after
+// the other with the lanes of the other types idle -- the pass is instruction-bound at 19 of 64 lanes on the conference scene (three types of similar
+// weight) -- which is the very thing the reference's per-material queues exist to avoid.  Here the 256 paths of a block hand the material step's inputs
+// (20 words: hit point, normal, uv, material, ray, light direction, throughput, seed) through LDS, sorted by BSDF type with ballot / popcount ranks, each
+// lane runs the step of the item in ITS slot -- a wave then holds one type, two at a boundary -- and the 16 result words travel back the same way.  Same
+// arithmetic per path, whichever lane does it: bit-identical.  Needs every thread of the block inside the pass (block barriers): launch_logic takes it only
+// when the path count is a multiple of the block size and `first` is off.  It is a template parameter, not a run-time flag: the worker item's 20 inputs on
+// top of the owner's state cost 119 VGPRs against 92 (4 instead of 5 waves per SIMD), which a scene that does not gain from it must not pay.  Round 6:
+// shipped where it wins -- same box, 16 M paths, pass alone / step: courtyard-1440p 2.44 -> 2.11 ms / +3.8 %, egyptcat 1.57 -> 1.47 / +3.4 %, conference
+// 1.89 -> 1.91 / -0.5 % (profiles/r05_regroup_ab.txt) -- i.e. for all-types scenes whose surfaces are mostly of ONE type (a wave of the plain pass then
+// runs that type's step at 2/3 of its lanes and every minority type's step at a handful), not for a scene of three types of similar weight; api.hip picks
+// per scene at upload (option "regroup").
+#ifndef LOGIC_REGROUP
+#define LOGIC_REGROUP 1
+#endif
+#ifndef LOGIC_REGROUP_MIN_BLOCKS      // blocks per CU the regrouped pass is compiled for (x 4 waves per block / 4 SIMDs = waves per SIMD)
+#define LOGIC_REGROUP_MIN_BLOCKS 5
+#endif
 
 struct LogicAux {
     uint8_t *member;          // numTasks
@@ -144,18 +162,15 @@ __device__ __forceinline__ uint32_t material_list(int type, uint32_t separate)
 #ifndef LOGIC_MIN_BLOCKS        // blocks per CU the register allocator must leave room for (x LOGIC_BLOCK / 256 waves per SIMD); 0: whatever it needs
 #define LOGIC_MIN_BLOCKS 0
 #endif
-#if LOGIC_MIN_BLOCKS
-#define LOGIC_BOUNDS __launch_bounds__(LOGIC_BLOCK, LOGIC_MIN_BLOCKS)
-#else
-#define LOGIC_BOUNDS __launch_bounds__(LOGIC_BLOCK)
-#endif
-template <int FUSE, bool RAW = false>
-__global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, Queues qs, uint32_t firstIteration)
+template <int FUSE, bool RAW = false, bool REGROUP = false>
+__global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : LOGIC_MIN_BLOCKS) > 0 ? (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : LOGIC_MIN_BLOCKS) : 1) void k_logic(State st, Scene sc, Frame fr, flx_render_params p, LogicAux aux, Queues qs, uint32_t firstIteration)
 {
     const uint32_t gid = blockIdx.x * LOGIC_BLOCK + threadIdx.x;
     uint32_t maxId = st.numTasks;
     if (firstIteration) { uint32_t npix = p.width * p.height; maxId = npix < maxId ? npix : maxId; }
     uint32_t member = 0u;
+    __shared__ uint32_t s_item[REGROUP ? 20 : 1][LOGIC_BLOCK];                        // [word][slot]: the material step's inputs, then its results
+    __shared__ uint32_t s_tc[5][LOGIC_BLOCK / 64];                                    // per wave: lanes with work of BSDF class 0..4
 
     if (gid < maxId) {
         const float4 thr = rd4(st.at(S_THR, gid));
@@ -416,7 +431,70 @@ __global__ LOGIC_BOUNDS void k_logic(State st, Scene sc, Frame fr, flx_render_pa
 
         MatStep o;
         o.bsdfNEE = mk3(0.0f); o.bsdfPdfW = 0.0f; o.singular = 0u; o.newT = T; o.orig = mk3(0.0f); o.pdfW = 0.0f; o.newDir = mk3(0.0f);
-        if (!terminate) {
+        bool regrouped = false;
+        if constexpr (REGROUP) {                                      // (compile-time: k_logic<USE_ALL, true, true>; every thread of the block is here: launch_logic)
+            regrouped = true;
+            const bool work = !terminate && inlined;
+            const uint32_t wv = threadIdx.x >> 6;
+            uint32_t cls = 4u;                                        // BSDF class 0 diffuse .. 4 delta / anything else
+            if (work) { const uint32_t c_ = material_list(mat.type, 1u); cls = c_ ? c_ - 1u : 4u; }
+            uint64_t bt[5];
+            #pragma unroll
+            for (int t = 0; t < 5; t++) bt[t] = __ballot(work && cls == (uint32_t)t);
+            if ((threadIdx.x & 63u) == 0u) { for (int t = 0; t < 5; t++) s_tc[t][wv] = (uint32_t)__popcll(bt[t]); }
+            __syncthreads();
+            uint32_t slot = 0u, total = 0u;
+            #pragma unroll
+            for (int t = 0; t < 5; t++) {
+                uint32_t before = 0u, all = 0u;
+                for (uint32_t w = 0; w < LOGIC_BLOCK / 64; w++) { const uint32_t n_ = s_tc[t][w]; all += n_; if (w < wv) before += n_; }
+                if (cls == (uint32_t)t) slot = total + before + mbcnt(bt[t]);
+                total += all;
+            }
+            if (work) {
+                const f3 L = haveL ? Lnee : Lold;
+                s_item[0][slot] = __float_as_uint(hitP.x); s_item[1][slot] = __float_as_uint(hitP.y); s_item[2][slot] = __float_as_uint(hitP.z);
+                s_item[3][slot] = __float_as_uint(hitN.x); s_item[4][slot] = __float_as_uint(hitN.y); s_item[5][slot] = __float_as_uint(hitN.z);
+                s_item[6][slot] = __float_as_uint(hitUV.x); s_item[7][slot] = __float_as_uint(hitUV.y);
+                s_item[8][slot] = (uint32_t)hitMat; s_item[9][slot] = backface ? 1u : 0u;
+                s_item[10][slot] = __float_as_uint(rayDir.x); s_item[11][slot] = __float_as_uint(rayDir.y); s_item[12][slot] = __float_as_uint(rayDir.z);
+                s_item[13][slot] = __float_as_uint(L.x); s_item[14][slot] = __float_as_uint(L.y); s_item[15][slot] = __float_as_uint(L.z);
+                s_item[16][slot] = __float_as_uint(T.x); s_item[17][slot] = __float_as_uint(T.y); s_item[18][slot] = __float_as_uint(T.z);
+                s_item[19][slot] = seed;
+            }
+            __syncthreads();
+            const uint32_t k = threadIdx.x;
+            if (k < total) {                                          // the item in MY slot: someone's path of (mostly) my wave's BSDF type
+                SurfHit h;
+                h.P = mk3(__uint_as_float(s_item[0][k]), __uint_as_float(s_item[1][k]), __uint_as_float(s_item[2][k]));
+                h.N = mk3(__uint_as_float(s_item[3][k]), __uint_as_float(s_item[4][k]), __uint_as_float(s_item[5][k]));
+                h.uv = mk2(__uint_as_float(s_item[6][k]), __uint_as_float(s_item[7][k]));
+                const int mid = (int)s_item[8][k]; const bool bf = s_item[9][k] != 0u;
+                const f3 dIn = mk3(__uint_as_float(s_item[10][k]), __uint_as_float(s_item[11][k]), __uint_as_float(s_item[12][k]));
+                const f3 Lk = mk3(__uint_as_float(s_item[13][k]), __uint_as_float(s_item[14][k]), __uint_as_float(s_item[15][k]));
+                const f3 Tk = mk3(__uint_as_float(s_item[16][k]), __uint_as_float(s_item[17][k]), __uint_as_float(s_item[18][k]));
+                uint32_t sk = s_item[19][k];
+                const MatStep r_ = material_step<FUSE>(sc, h, sc.materials[mid], bf, dIn, Lk, Tk, &sk);
+                s_item[0][k] = __float_as_uint(r_.bsdfNEE.x); s_item[1][k] = __float_as_uint(r_.bsdfNEE.y); s_item[2][k] = __float_as_uint(r_.bsdfNEE.z);
+                s_item[3][k] = __float_as_uint(r_.bsdfPdfW); s_item[4][k] = r_.singular;
+                s_item[5][k] = __float_as_uint(r_.newT.x); s_item[6][k] = __float_as_uint(r_.newT.y); s_item[7][k] = __float_as_uint(r_.newT.z);
+                s_item[8][k] = __float_as_uint(r_.orig.x); s_item[9][k] = __float_as_uint(r_.orig.y); s_item[10][k] = __float_as_uint(r_.orig.z);
+                s_item[11][k] = __float_as_uint(r_.pdfW);
+                s_item[12][k] = __float_as_uint(r_.newDir.x); s_item[13][k] = __float_as_uint(r_.newDir.y); s_item[14][k] = __float_as_uint(r_.newDir.z);
+                s_item[15][k] = sk;
+            }
+            __syncthreads();
+            if (work) {
+                o.bsdfNEE = mk3(__uint_as_float(s_item[0][slot]), __uint_as_float(s_item[1][slot]), __uint_as_float(s_item[2][slot]));
+                o.bsdfPdfW = __uint_as_float(s_item[3][slot]); o.singular = s_item[4][slot];
+                o.newT = mk3(__uint_as_float(s_item[5][slot]), __uint_as_float(s_item[6][slot]), __uint_as_float(s_item[7][slot]));
+                o.orig = mk3(__uint_as_float(s_item[8][slot]), __uint_as_float(s_item[9][slot]), __uint_as_float(s_item[10][slot]));
+                o.pdfW = __uint_as_float(s_item[11][slot]);
+                o.newDir = mk3(__uint_as_float(s_item[12][slot]), __uint_as_float(s_item[13][slot]), __uint_as_float(s_item[14][slot]));
+                seed = s_item[15][slot];
+            }
+        }
+        if (!terminate && !regrouped) {
             if (inlined) {
                 // the material kernel's step for this path (material.hip: material_body), fed from registers.  The "stored light
                 // direction" is this iteration's sample when NEE stored one, else whatever the record holds (the material kernels
@@ -607,6 +685,25 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
         r += mbcnt(bal[0] | bal[2] | bal[3] | bal[4] | bal[5] | bal[6]);
         qs.q[FLX_Q_EXTENSION][ext_len(qs) + r] = gid;
     }
+    if (fuse != 0 && byPathId == 3u && ((member & 1u) != 0u || ml != 0u)) {
+        // ext order 3 (api.hip: EARLY EXTENSION START): the same set as order 2 in TWO segments, each in path-id order --
+        //   A  the continuing paths whose material step this pass has inlined: their new rays are complete when this pass is, so the persistent closest-hit
+        //      kernel starts on them at once, beside genRays and the material kernel of the other BSDF types;
+        //   B  the regenerated paths and the continuing paths of the types that are not inlined: traced behind those two kernels.
+        // |A| = the final counters of the inlined lists (the scan ran before this kernel).
+        const bool inA = ml != 0u && fuse_inlines_list(fuse, ml);
+        uint32_t r = 0u, nA = 0u;
+        uint64_t mA = 0ull, mB = bal[0];
+        #pragma unroll
+        for (int l = 2; l < NUM_LISTS; l++) {
+            const bool a = fuse_inlines_list(fuse, (uint32_t)(l - 1));
+            if (a) { mA |= bal[l]; nA += qs.counters[FLX_Q_DIFFUSE + (l - 2)]; } else mB |= bal[l];
+            if (a == inA) { r += s_off[l]; for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w]; }
+        }
+        if (!inA) { r += s_off[0]; for (uint32_t w = 0; w < wave; w++) r += s_cnt[0][w]; }
+        r += mbcnt(inA ? mA : mB);
+        qs.q[FLX_Q_EXTENSION][ext_len(qs) + (inA ? 0u : nA) + r] = gid;
+    }
 }
 
 // elements per list in the block-count / block-offset arrays (api.hip allocates NUM_LISTS x this, zero-filled)
@@ -628,11 +725,13 @@ uint32_t fused_queue_mask(int fuse)
 // fuse: 0 = the plain logic kernel | USE_DIFFUSE | USE_ALL  (diffuse + glossy was measured too: never the best of the three)
 void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const Frame &fr, const flx_render_params &p,
                   uint8_t *member, uint32_t *blockCounts, uint32_t *blockOffsets, int firstIteration, int fuse, int raygenFirst, int extByPathId, int raw,
-                  unsigned long long *lookback, uint32_t epoch, int regen, int regenAppendExt, uint32_t *error)
+                  unsigned long long *lookback, uint32_t epoch, int regen, int regenAppendExt, uint32_t *error, int regroup)
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
     LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks), lookback, epoch, (uint32_t)(raw && regen), (uint32_t)regenAppendExt, error};
+    // the BSDF-uniform material step needs every thread of every block inside the pass (block barriers): whole blocks of paths, no `first` cut-off
+    const bool rg = LOGIC_REGROUP && raw && regroup && fuse == USE_ALL && !firstIteration && st.numTasks % LOGIC_BLOCK == 0u;
     const dim3 g(blocks), b(LOGIC_BLOCK);
     switch (fuse) {
     case USE_DIFFUSE:
@@ -640,7 +739,8 @@ void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene 
         else hipLaunchKernelGGL((k_logic<USE_DIFFUSE, false>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
         break;
     case USE_ALL:
-        if (raw) hipLaunchKernelGGL((k_logic<USE_ALL, true>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
+        if (rg) hipLaunchKernelGGL((k_logic<USE_ALL, true, true>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
+        else if (raw) hipLaunchKernelGGL((k_logic<USE_ALL, true>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
         else hipLaunchKernelGGL((k_logic<USE_ALL, false>), g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration);
         break;
     default: fuse = 0; hipLaunchKernelGGL(k_logic<0>, g, b, 0, s, st, sc, fr, p, aux, qs, (uint32_t)firstIteration); break;

@@ -152,7 +152,9 @@ enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FL
        FLX_K_POSTPROCESS = 6,
        FLX_K_TRACE_SPAN = 7,   /* start of the extension kernel .. end of the (concurrent) shadow kernel */
        FLX_K_LOGIC_FUSED = 8,  /* logic + the inlined material step as one pass (option "fuse"); FLX_K_MATERIALS then covers the rest */
-       FLX_K_COUNT = 9 };
+       FLX_K_EXTEND_B = 9,     /* option "early_ext": the extension kernel's second launch (regenerated paths + paths of the BSDF types the fused pass does not inline);
+                                  FLX_K_EXTEND is then the first launch, on the paths whose material step the fused pass inlined */
+       FLX_K_COUNT = 10 };
 /* on: 0 off | 1 time every kernel | 2 time only the two trace kernels (+ their span), as the reference does | 3 only the
  * extension kernel | 4 the three kernels bench.py prices against a roof: extension, logic (the fused pass incl. its queue scan + scatter), shadow.
  * Each event pair costs a few microseconds of stream time, which shows at ~11 launches per 0.7 ms

@@ -43,8 +43,15 @@ def build_ref(force=False):
     out = os.path.join(HERE, "_ref", "libfluctus_ref.so")
     marker = os.path.join(HERE, "_ref", "gfx950", "ieee", "traceExtension.co")
     dep = glob.glob(os.path.join(HERE, "ref", "*"))
-    if force or _stale(out, dep) or _stale(marker, dep):
+    if force or _stale(out, dep):
         _run(["make", "-C", os.path.join(HERE, "ref"), "-j8"])
+    if force or _stale(marker, dep):
+        # the gfx950 leg depends on the image's device-libs layout: a failure here is reported, not fatal (the x86 pin and the CPU tests do not need it;
+        # tests/test_gpu_ref_gfx950.py then fails loudly on the GPU box instead of silently passing)
+        try:
+            _run(["make", "-C", os.path.join(HERE, "ref"), "-j8", "gfx950"])
+        except RuntimeError as e:
+            print(f"[oracle build] WARNING: gfx950 build of the reference kernels failed ({e}); Pin 5 will be unavailable", flush=True)
     return out
 
 

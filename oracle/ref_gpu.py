@@ -40,6 +40,11 @@ def available(flavour="ieee"):
     return os.path.exists(os.path.join(co_dir(flavour), "traceExtension.co"))
 
 
+def available_env(flavour="ieee"):
+    """the USE_ENV_MAP variants of `logic`, built with the image stand-in (oracle/ref/gfx950_image_standin.cl)"""
+    return os.path.exists(os.path.join(co_dir(flavour), "logic_v14_imgstandin.co"))
+
+
 # ------------------------------------------------------------------------------------------------ OpenCL backend
 class _OpenCL:
     name = "opencl"
@@ -353,6 +358,7 @@ class RefGpuContext:
         B.write(self.prob, np.ones(1, np.float32)); B.write(self.pdf, np.ones(1, np.float32)); B.write(self.alias, np.zeros(1, np.int32))
         B.write(self.counters, np.zeros(8, np.uint32)); B.write(self.curr_pixel, np.zeros(1, np.uint32))
         B.write(self.tasks, np.zeros(NUM_COLS * N, np.float32))
+        self.env_img = None                       # {w, h, 0, 0, float4 texels[]} for the image stand-in builds of `logic` (upload_envmap)
         self._k = {}
         self.last_ms = {}
         self.timed = False
@@ -372,7 +378,7 @@ class RefGpuContext:
 
     def close(self):
         B = self.B
-        for b in [self.tasks, self.counters, self.curr_pixel, self.params_buf, self.prob, self.alias, self.pdf] + self.queues + list(self.scene.values()) + self.fb:
+        for b in [self.tasks, self.counters, self.curr_pixel, self.params_buf, self.prob, self.alias, self.pdf, self.env_img] + self.queues + list(self.scene.values()) + self.fb:
             B.free(b)
         self.tasks = None
 
@@ -385,7 +391,26 @@ class RefGpuContext:
             B.write(self.scene[k], arr)
 
     def upload_envmap(self, e):
-        raise ImageArgUnsupported("gfx950 has no image support: the env map (read_imagef) cannot run on this device")
+        """gfx950 has no image support (CL_DEVICE_IMAGE_SUPPORT = 0), so no runtime can create the image2d_t `logic` expects.  Through the HIP module
+        loader the kernel's 8-byte image slot takes a plain pointer, and the logic_v<id>_imgstandin.co builds (oracle/ref/Makefile GERULE: the reference's
+        wf_logic.cl unmodified, AMD's built-in library for everything EXCEPT read_imagef / get_image_dim, which come from the builder-written
+        oracle/ref/gfx950_image_standin.cl) read {int w, h, 0, 0; float4 texels[w * h]} behind it.  A stand-in for the image filter only; labelled so."""
+        if self.B.name != "hip":
+            raise ImageArgUnsupported("gfx950 has no image support: the env map needs the hip loader and the image stand-in build (backend_name='hip')")
+        if not available_env(self.flavour):
+            raise RefGpuUnavailable(f"{co_dir(self.flavour)}/logic_v*_imgstandin.co not built (make -C oracle/ref gfx950)")
+        B = self.B
+        w, h = int(e.w), int(e.h)
+        rgb = np.ascontiguousarray(e.rgb, np.float32).reshape(w * h, 3)
+        img = np.zeros(4 + 4 * w * h, np.float32)
+        img[:4].view(np.int32)[:2] = (w, h)
+        tex = img[4:].reshape(w * h, 4)
+        tex[:, :3] = rgb; tex[:, 3] = 1.0
+        for b in (self.env_img, self.prob, self.alias, self.pdf):
+            B.free(b)
+        self.env_img = B.alloc(img.nbytes); B.write(self.env_img, img)
+        self.prob, self.alias, self.pdf = B.alloc(4 * w * h), B.alloc(4 * w * h), B.alloc(4 * w * h)
+        B.write(self.prob, np.ascontiguousarray(e.prob, np.float32)); B.write(self.alias, np.ascontiguousarray(e.alias, np.int32)); B.write(self.pdf, np.ascontiguousarray(e.pdf, np.float32))
 
     def set_params(self, p):
         self.params = p.copy()
@@ -432,15 +457,15 @@ class RefGpuContext:
 
     def wf_logic(self, first=False):
         v = self.logic_variant()
-        if v & 2:
-            raise ImageArgUnsupported("logic with USE_ENV_MAP samples an image: not runnable on gfx950")
+        if (v & 2) and self.env_img is None:
+            raise ImageArgUnsupported("logic with USE_ENV_MAP samples an image: on gfx950 only through the image stand-in build (hip loader + upload_envmap)")
         n = ((self.num_tasks - 1) // 32 + 1) * 32
         s, q = self.scene, self.queues
         pixels, denAlbedo, denNormal = self.fb[0], self.fb[4], self.fb[5]
         args = [self.tasks, pixels, denNormal, denAlbedo, self.counters, q[Q_EXTENSION], q[Q_SHADOW], q[Q_RAYGEN], q[Q_DIFFUSE], q[Q_GLOSSY], q[Q_GGX_REFL],
-                q[Q_GGX_REFR], q[Q_DELTA], s["tris"], s["nodes"], s["indices"], None, self.prob, self.alias, self.pdf, s["materials"], s["texdata"], s["texdesc"],
+                q[Q_GGX_REFR], q[Q_DELTA], s["tris"], s["nodes"], s["indices"], (self.env_img if (v & 2) else None), self.prob, self.alias, self.pdf, s["materials"], s["texdata"], s["texdesc"],
                 self.params_buf, _U32(self.num_tasks), _U32(1 if first else 0)]
-        self._run("logic", self._kernel(f"logic_v{v}", "logic"), [n], args)
+        self._run("logic", self._kernel(f"logic_v{v}_imgstandin" if (v & 2) else f"logic_v{v}", "logic"), [n], args)
 
     def _mat(self, entry, q):
         s = self.scene

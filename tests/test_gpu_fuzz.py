@@ -44,7 +44,7 @@ def _gen_sequence(rng):
             op = chain[pos % len(chain)]; pos += 1
         else:
             op = rng.choice(["logic", "raygen", "materials", "extend", "shadow", "clear", "counters", "finish", "params", "export", "qread",
-                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals", "opt_regen"])
+                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals", "opt_regen", "opt_regroup", "opt_early"])
         if op == "logic":
             if logic_done:
                 continue
@@ -75,6 +75,10 @@ def _gen_sequence(rng):
             seq.append(("opt", "fuse_set", int(rng.choice([1, 31]))))
         elif op == "opt_regen":                       # in-kernel regeneration of the fused RAW pass (logic.hip: REGEN) on / off
             seq.append(("opt", "regen", int(rng.randint(0, 2))))
+        elif op == "opt_regroup":                     # all-types RAW pass with its material step sorted by BSDF type through LDS (logic.hip: LOGIC_REGROUP) on / off
+            seq.append(("opt", "regroup", int(rng.randint(0, 2))))
+        elif op == "opt_early":                       # extension queue in two segments, the first traced behind `logic` alone on a third stream (api.hip: EARLY EXTENSION START)
+            seq.append(("opt", "early_ext", int(rng.choice([0, 6, 28]))))
         elif op == "opt_overlap":
             seq.append(("opt", "overlap", int(rng.choice([0, 1, 2]))))
         elif op == "pixidx":
@@ -89,12 +93,13 @@ def _gen_sequence(rng):
     return seq
 
 
-@pytest.mark.parametrize("separate_queues,seed", [(1, 20260929), (0, 7), (1, 12345)])
-def test_call_sequence_fuzz(separate_queues, seed):
+# n: 4096 + 37 = a ragged last block; 17 x 256 = whole blocks, which the BSDF-regrouped all-types pass needs (block barriers: logic.hip LOGIC_REGROUP) -- round 6
+@pytest.mark.parametrize("separate_queues,seed,n", [(1, 20260929, 4096 + 37), (0, 7, 4096 + 37), (1, 12345, 4096 + 37), (1, 606, 17 * 256), (0, 607, 17 * 256)])
+def test_call_sequence_fuzz(separate_queues, seed, n):
     from fluctus_amd.device import HipContext
     from oracle.binding import OracleContext
     d = common.mixed_material_scene()
-    w, h, n = 64, 48, 4096 + 37
+    w, h = 64, 48
     npix = w * h
     p = common.scene_params(d, w, h, maxBounces=5, useAreaLight=1, useEnvMap=1, wfSeparateQueues=separate_queues)
     env = host.synthetic_sky(64, 32)
@@ -143,11 +148,12 @@ def test_call_sequence_fuzz(separate_queues, seed):
         hi = sg.view(np.uint32)[COL.HIT_I]
         exported_raw += int((((hi >> 30) & 3) == 1).sum())
 
-    def run(seq, fuse_set, ext_order, regen, what, check_each=False):
+    def run(seq, fuse_set, ext_order, regen, regroup, early, what, check_each=False):
         nonlocal cursor
         g.set_option("fuse", 1); g.set_option("extend_tree", 4); g.set_option("refill_extend", 16 | (32 << 8)); g.set_option("overlap", 2)
         g.set_option("shadow_tree", 4); g.set_option("refill_shadow", 0)
         g.set_option("fuse_set", fuse_set); g.set_option("ext_order", ext_order); g.set_option("regen", regen)
+        g.set_option("regroup", regroup); g.set_option("early_ext", early)
         for c in (g, o):
             c.set_params(p)
         for k, op in enumerate(seq):
@@ -208,14 +214,16 @@ def test_call_sequence_fuzz(separate_queues, seed):
         # (the shipped default of the diffuse-only pass: the scatter writes the regenerated paths' entries and the deferred genRays must not append)
         ext_order = int(rng.choice([0, 1, 2]))
         regen = int(rng.randint(0, 2))                 # the fused RAW pass regenerates its terminating paths itself (logic.hip: REGEN) | genRays does
+        regroup = int(rng.randint(0, 2))               # the all-types RAW pass sorts its material step by BSDF type per block (takes effect with whole blocks of paths)
+        early = int(rng.choice([0, 6, 28]))            # early start of the closest-hit kernel on the inlined paths' segment of the queue (0 off | waves per CU)
         # every sequence starts from the oracle's current state, queues cleared
         for c in (g, o):
             c.clear_queues()
         common.sync(g, o)
         start, cursor0 = o.state_export(), cursor
-        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}, regen {regen}) {seq}"
+        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}, regen {regen}, regroup {regroup}, early_ext {early}) {seq}"
         try:
-            run(seq, fuse_set, ext_order, regen, what)
+            run(seq, fuse_set, ext_order, regen, regroup, early, what)
         except AssertionError:
             # locate the call: same sequence from the same state, everything compared after every call
             for c in (g, o):
@@ -223,7 +231,7 @@ def test_call_sequence_fuzz(separate_queues, seed):
             cursor = cursor0
             for c in (g, o):
                 set_cursor(c)
-            run(seq, fuse_set, ext_order, regen, what, check_each=True)
+            run(seq, fuse_set, ext_order, regen, regroup, early, what, check_each=True)
             raise
     assert exported_raw == 0, f"{exported_raw} RAW hit records were exported"
     phases = sorted({c[0] for c in covered})

@@ -126,13 +126,15 @@ def test_bench_rccl_path_single_rank(tmp_path):
     port = 29600 + os.getpid() % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
-           "--num-tasks", "262144", "--width", "640", "--height", "360", "--no-cpu-baseline"]
+           "--num-tasks", "262144", "--width", "640", "--height", "360", "--no-cpu-baseline", "--scaling", "strong"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["value"] > 0
+    # --scaling strong: the paths in flight are fixed over the whole job (num_tasks // world per rank; one rank here), and the line says so
+    assert j["scaling"] == "strong" and j["config"]["num_tasks_per_gpu"] == 262144 and j["config"]["num_tasks_whole_job"] == 262144 and j["config"]["scaling_mode"].startswith("strong")
     assert "gather_ms" in j and j["gather_ms"] > 0
     assert j["gather_matches_read_pixels"] is True
     assert j["gather_native_matches_torch"] is True and j["gather_ms_native_rccl"] > 0     # flx_group_init + flx_gather beside torch's

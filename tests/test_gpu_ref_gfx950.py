@@ -16,9 +16,13 @@ state, queues and counters; both run the one kernel; then
   * float columns: SURVEY 8(c)'s tolerances -- rel 1e-5 / abs 1e-6 for plain arithmetic (RTOL/ATOL below, doubled as in the x86 pin),
     rel 1e-4 downstream of atan2 / acos / native_sin / native_cos (GGX lobe), 1e-3 for GGX pdf values (ill-conditioned: common.sharp_lobe_paths);
   * the framebuffer: counts exact, sums within the any-order bound (common.fb_close) widened by the float tolerance of the terms.
-`logic` with USE_ENV_MAP calls read_imagef and gfx950 has no image support, so env-map scenes are pinned for genRays / materials /
-traceExtension / traceShadow only (logic then runs on the device context alone); logic without the env map runs through the HIP module
-loader on the same code object if the OpenCL runtime will not take a null image handle (oracle/ref_gpu.py).
+`logic` with USE_ENV_MAP calls read_imagef and gfx950 has no image support.  Round 6: those 16 variants are built a second way
+(logic_v<id>_imgstandin.co, oracle/ref/Makefile GERULE): the reference's wf_logic.cl unmodified, AMD's built-in library for everything EXCEPT
+read_imagef / get_image_dim, which come from the builder-written oracle/ref/gfx950_image_standin.cl (OpenCL 1.2 s8.2 restated) -- a STAND-IN for the
+image filter, labelled so in every report (`logic_image_standin`), and by the task's rules it upgrades no pin.  What it buys: the env-map branch of
+`logic` -- alias sampling, envMapPdf, the MIS weights, sin / cos / acos / atan2 of the direction <-> uv maps -- now meets AMD's library AS THE KERNEL,
+in lockstep with the HIP kernel on the same GPU, leaving one function on trust instead of the whole branch.  logic without the env map runs through
+the HIP module loader on the stand-in-free code object if the OpenCL runtime will not take a null image handle (oracle/ref_gpu.py).
 """
 import json
 import os
@@ -89,7 +93,7 @@ def _need_ref():
 def _report(name, payload):
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r05_ref_gfx950.json")
+    path = os.path.join(out_dir, "r06_ref_gfx950.json")
     try:
         j = json.load(open(path))
     except Exception:
@@ -195,7 +199,13 @@ def _lockstep(d, p, n, iters, env=None, tag=""):
     r.upload_scene(d); r.set_params(p)
     rl = r                                        # context that runs `logic`
     npix = int(p["width"]) * int(p["height"])
-    stats = dict(ext_rays=0, flips=0, shadow_rays=0, shadow_flips=0, logic_backend=None, kernels=0)
+    stats = dict(ext_rays=0, flips=0, shadow_rays=0, shadow_flips=0, logic_backend=None, kernels=0, logic_kernels=0, logic_image_standin=False)
+    if use_env:
+        # USE_ENV_MAP: the image stand-in build of `logic` through the HIP module loader (module docstring); everything else stays on the OpenCL runtime
+        assert rg.available_env("ieee"), "oracle/_ref/gfx950/ieee/logic_v*_imgstandin.co missing (make -C oracle/ref gfx950)"
+        rl = rg.RefGpuContext(n, backend_name="hip", flavour="ieee")
+        rl.upload_scene(d); rl.upload_envmap(env); rl.set_params(p)
+        stats["logic_image_standin"] = True
     # reset itself
     g.wf_reset(); r.wf_reset()
     _cmp(g, r, d, f"{tag} reset", "reset", stats)
@@ -205,9 +215,6 @@ def _lockstep(d, p, n, iters, env=None, tag=""):
         steps = [("logic", lambda c: c.wf_logic(False)), ("raygen", lambda c: c.wf_raygen()), ("materials", lambda c: c.wf_materials())]
         cnt = None
         for name, fn in steps:
-            if name == "logic" and use_env:
-                fn(g)                             # read_imagef: not runnable on gfx950 (module docstring)
-                continue
             tgt = rl if name == "logic" else r
             _sync_ref(tgt, g)
             try:
@@ -224,6 +231,7 @@ def _lockstep(d, p, n, iters, env=None, tag=""):
             stats["logic_backend"] = rl.B.name
             _cmp(g, tgt, d, f"{tag} it{it} {name}", name, stats)
             stats["kernels"] += 1
+            stats["logic_kernels"] += int(name == "logic")
         cnt = g.get_counters(); g.finish()
         cnt = np.array(cnt, copy=True)
         for name, fn in (("extend", lambda c: c.wf_extend()), ("shadow", lambda c: c.wf_shadow())):
@@ -239,6 +247,7 @@ def _lockstep(d, p, n, iters, env=None, tag=""):
     g.postprocess(); r.postprocess(); g.finish(); r.finish()
     assert np.allclose(g.read_pixels(1), r.read_pixels(1), rtol=1e-4, atol=1e-5), f"{tag}: resolved preview image"
     _report(f"lockstep_{tag}", stats)
+    assert stats["logic_kernels"] == iters, stats          # `logic` ran on the reference side in every iteration, env map or not
     assert stats["flips"] <= max(1, int(FLIP_BUDGET * stats["ext_rays"])), stats
     assert stats.get("hit_err_above_tol", 0) <= max(2, OUTLIER_FRAC * 4 * stats.get("hit_records", 0)), stats
     assert stats["shadow_flips"] <= max(1, int(FLIP_BUDGET * stats["shadow_rays"])), stats
@@ -271,8 +280,10 @@ def test_opencl_runtime_loads_the_reference_code_objects():
     (1, 0, 1, 0, 1, 0),
     (1, 0, 0, 1, 1, 0),
     (0, 0, 1, 1, 1, 1),
-    (1, 1, 1, 1, 1, 0),          # env map on: every kernel but logic
+    (1, 1, 1, 1, 1, 0),          # env map on: `logic` through the image stand-in build (module docstring), every other kernel stand-in-free
     (0, 1, 1, 1, 0, 1),
+    (0, 1, 1, 0, 1, 0),          # env map, explicit sampling only / implicit only: the other two env-map code paths of wf_logic.cl:84-107, 226-256
+    (0, 1, 0, 1, 1, 1),
 ])
 def test_all_bsdfs_flag_matrix_vs_reference_on_gfx950(area, env, expl, impl, sep, roulette):
     """All six BSDFs + textures + normal map, area-light NEE / MIS, separate vs single material queue, Russian roulette: the flag matrix of
@@ -322,10 +333,14 @@ def test_reference_on_gfx950_reproduces_the_x86_fixtures(tag):
     worst = {}
     for k in range(1, len(names)):
         name = names[k]
-        if name not in ("logic", "raygen", "materials", "extend", "shadow") or (name == "logic" and use_env):
+        if name not in ("logic", "raygen", "materials", "extend", "shadow"):
             continue
         c = r
-        if name == "logic" and _logic_backend[0] == "hip":
+        if name == "logic" and use_env:               # the image stand-in build (module docstring): the fixture's own environment map
+            c = rg.RefGpuContext(n, backend_name="hip", flavour="ieee"); c.upload_scene(d)
+            ew, eh = int(z["env_wh"][0]), int(z["env_wh"][1])
+            c.upload_envmap(host.EnvMap(ew, eh, z["env_rgb"], z["env_prob"], z["env_alias"], z["env_pdf"])); c.set_params(p)
+        elif name == "logic" and _logic_backend[0] == "hip":
             c = _ref_ctx(n, for_logic=True); c.upload_scene(d); c.set_params(p)
         fn = {"logic": lambda: c.wf_logic(False), "raygen": c.wf_raygen, "materials": c.wf_materials, "extend": c.wf_extend, "shadow": c.wf_shadow}[name]
         for attempt in (0, 1):
@@ -367,9 +382,39 @@ def test_reference_on_gfx950_reproduces_the_x86_fixtures(tag):
         worst[name] = max(worst.get(name, 0.0), float(rel.max()))
         if c is not r:
             c.close()
-    assert ran.get("extend") and ran.get("shadow") and ran.get("raygen") and ran.get("materials"), ran
+    assert ran.get("extend") and ran.get("shadow") and ran.get("raygen") and ran.get("materials") and ran.get("logic"), ran
     _report(f"x86_fixture_{tag}", {"kernels_run": ran, "max_rel_diff_gfx950_builtins_vs_x86_standin": worst})
     r.close()
+
+
+def test_kitchen_env_logic_1M_paths_vs_reference_on_gfx950():
+    """The headline workload's own `logic` variant (USE_ENV_MAP + SAMPLE_EXPLICIT + SAMPLE_IMPLICIT, separate queues: logic_v14) on 2^20 paths of the
+    kitchen's steady state under night.hdr: the reference's kernel (image stand-in build, module docstring) and k_logic<0> from the same state --
+    counters exact, queues as sets, integer columns exact, floats at the `logic` tolerance, framebuffer counts exact.  1 M paths exercise what the
+    4 096-path lockstep scenes cannot: every bright texel of the real map's alias table, grazing implicit hits, the whole range of path lengths."""
+    rg = _need_ref()
+    import bench
+    n = 1 << 20
+    d, p, env = bench.build_workload(name="kitchen")
+    g = _hip_ctx(n, ext=4, shadow=4)
+    g.upload_scene(d); g.upload_envmap(env); g.set_params(p)
+    driver.reset_renderer(g)
+    npix = int(p["width"]) * int(p["height"])
+    for _ in range(2 * int(p["maxBounces"]) + 2):
+        driver.benchmark_iteration(g, npix)
+    r = rg.RefGpuContext(n, backend_name="hip", flavour="ieee")
+    r.upload_scene(d); r.upload_envmap(env); r.set_params(p)
+    stats = dict(ext_rays=0, flips=0, shadow_rays=0, shadow_flips=0)
+    for it in range(2):
+        _sync_ref(r, g)
+        g.wf_logic(False); r.wf_logic(False)
+        _cmp(g, r, d, f"kitchen 1M logic it{it}", "logic", stats)
+        cnt = np.array(g.get_counters(), copy=True); g.finish()
+        g.wf_raygen(); g.wf_materials(); g.wf_extend(); g.wf_shadow(); g.clear_queues(); g.finish()
+        g.pixel_index_update(npix, int(cnt[Q.RAYGEN]))
+    c = g.get_counters(); g.finish()
+    _report("kitchen_1M_env_logic", {"paths": n, "iterations": 2, "logic_image_standin": True, "variant": r.logic_variant()})
+    r.close(); g.close()
 
 
 def _steady_state(workload, n, iters):

@@ -390,73 +390,85 @@ def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""
     fb0 = g.read_pixels(0) if start_iterations else None
     common_state = [None, 0, 0]                           # oracle state, cursor, iteration count at the last point both sides were identical
     explained = []
+    ray_counts = {}                                       # iteration -> the oracle's raygen-queue length of the main run (what both pixel cursors were advanced by)
     shifted_total, last_shifted = [0], [0]                # paths whose pixel moved behind a tie that changed its path's termination (explain_forks)
 
     def explain_forks(bad_paths, upto, what, sg_main, so_main):
-        """A path whose state differs at a checkpoint must have been forked by a TIE: replay the stretch since the last common state on
-        both sides, this time looking after every extension launch (the pattern of _free_run_default_vs_oracle), and demand that every
-        differing path shows, at the launch where it first differs, hit records that differ in `i` but agree in `t` to 1e-5 -- anything
-        else (a wrong commit in the fused RAW pass, a wrong traversal result) has no such launch and fails here.  The device's traversal
-        is deterministic per ray, so the replay reproduces the flip."""
+        """A path whose state differs at a checkpoint must have been forked by a TIE.  Two replays of the stretch since the last common state, both
+        looking after every extension launch (the pattern of _free_run_default_vs_oracle):
+          1. the DEVICE follows the oracle -- every path whose hit index differs at a launch must agree in `t` to 1e-5 there (a tie), everything else
+             must be bit-identical at every launch; anything else (a wrong commit in the fused RAW pass, a wrong traversal result) fails here;
+          2. (round 6; only if paths differ that replay 1 did not show tied) the ORACLE follows the device -- it adopts the device's hit records at
+             every tied launch and otherwise runs on its own -- and must arrive, bit for bit on EVERY path, at the state the device's undisturbed main
+             run reached (sg_main).  A tie can change WHETHER its path terminates in that iteration: the device's raygen queue then holds one path more
+             or fewer and every path regenerated behind it gets the neighbouring pixel (src/wf_raygen.cl:25: pixel = cursor + queue index) -- a
+             different camera ray, a different path from there on, for up to a fifth of the paths.  Round 5 accepted such paths by their pixel delta
+             alone; now the oracle itself, given nothing but the device's tie choices, has to reproduce every one of them.
+        The device's traversal is deterministic per ray, so the replays reproduce the main run's flips."""
         s0, cur0, it0 = common_state
         assert s0 is not None
         s1 = o.state_export()                             # where the main loop continues afterwards
-        for c in (g, o):
-            c.state_import(s0); c.pixel_index_reset(); c.pixel_index_update(npix, cur0)
-        tied = set()
-        cur = cur0
-        for j in range(it0, upto):
+
+        def replay(oracle_follows_device):
             for c in (g, o):
-                c.wf_logic(False); c.wf_raygen(); c.wf_materials()
-            cgj, coj = g.get_counters(), o.get_counters(); g.finish()
-            cgj, coj = np.array(cgj, copy=True), np.array(coj, copy=True)
-            assert (cgj == coj).all(), f"{workload} {what}: replay it{j}: counters {cgj} vs {coj}"
-            qo = o.queue_read(Q.EXTENSION)[:int(coj[Q.EXTENSION])]
-            g.wf_extend(); o.wf_extend(); g.finish()
-            sg, so = g.state_export(), o.state_export()
-            flip = np.zeros(sg.shape[1], bool)
-            flip[qo] = sg.view(np.uint32)[COL.HIT_I][qo] != so.view(np.uint32)[COL.HIT_I][qo]
-            fails = common.state_diff(sg, so, 0.0, 0.0, mask=~flip)
-            assert not fails, f"{workload} {what}: replay it{j} after extend, beyond hit-index flips: " + "; ".join(fails[:4])
-            if flip.any():
-                fr = np.nonzero(flip)[0]
-                assert np.allclose(sg[COL.HIT_T][fr], so[COL.HIT_T][fr], rtol=1e-5, atol=1e-6), f"{workload} {what}: replay it{j}: a flip that is not a tie in t"
-                tied.update(int(x) for x in fr)
-                g.state_import(so)
-            g.wf_shadow(); o.wf_shadow()
-            for c in (g, o):
-                c.clear_queues(); c.finish(); c.pixel_index_update(npix, int(coj[Q.RAYGEN]))
-            cur = (cur + int(coj[Q.RAYGEN])) % npix
-        # A tie can change WHETHER its path terminates in that iteration (a hit instead of a miss, another material): the raygen queue of the device then
-        # holds one path more or fewer, and every path regenerated behind it in id order gets the neighbouring pixel (src/wf_raygen.cl:25: pixel = cursor +
-        # queue index) -- a different camera ray, i.e. a different path from there on, for up to a fifth of the paths.  These are consequences of the tie, not
-        # forks of their own: a path whose PIXEL differs, by no more than the number of ties found, and which lies behind a tied path, is explained by it
-        # (16 M paths meet such a tie within five iterations; 8 M did not).  They are reported, not counted against the flip budget.
-        rest = set(int(x) for x in bad_paths) - tied
-        pg_, po_ = sg_main.view(np.uint32)[COL.PIXEL_INDEX].astype(np.int64), so_main.view(np.uint32)[COL.PIXEL_INDEX].astype(np.int64)
-        shifted = set()
-        if tied and rest:
-            first_tie = min(tied)
-            for x in rest:
-                dlt = abs(int(pg_[x] - po_[x])); dlt = min(dlt, npix - dlt)
-                if x > first_tie and 0 < dlt <= len(tied):
-                    shifted.add(x)
-        shifted_total[0] += len(shifted)
-        unexplained = sorted(rest - shifted)
-        if unexplained:                                   # diagnostics: which columns of the main run's states differ, and the replay's view of the same paths
-            sgr, sor = g.state_export(), o.state_export()
-            for x in unexplained[:4]:
-                cols = [c for c in range(64) if not skip[c] and sg_main.view(np.uint32)[c][x] != so_main.view(np.uint32)[c][x]]
-                print(f"[fork] path {x}: main run differs in " + ", ".join(f"{common.colname(c)}: {sg_main[c][x]!r}/{sg_main.view(np.uint32)[c][x]:#x} vs {so_main[c][x]!r}/{so_main.view(np.uint32)[c][x]:#x}" for c in cols))
-                colsr = [c for c in range(64) if not skip[c] and sgr.view(np.uint32)[c][x] != sor.view(np.uint32)[c][x]]
-                print(f"[fork] path {x}: after the replay device vs oracle differ in {[common.colname(c) for c in colsr]}")
-        assert not unexplained, f"{workload} {what}: paths {unexplained[:8]} differ from the oracle without a hit-index tie in the replay (ties found: {sorted(tied)[:8]})"
-        explained.extend(sorted(tied))
-        last_shifted[0] = len(shifted)
-        # the replay ends where the oracle stood (it is deterministic): continue the main loop from there on both sides
+                c.state_import(s0); c.pixel_index_reset(); c.pixel_index_update(npix, cur0)
+            tied_ = set()
+            cur_ = cur0
+            tagr = "replay 2 (oracle follows the device)" if oracle_follows_device else "replay"
+            for j in range(it0, upto):
+                for c in (g, o):
+                    c.wf_logic(False); c.wf_raygen(); c.wf_materials()
+                cgj, coj = g.get_counters(), o.get_counters(); g.finish()
+                cgj, coj = np.array(cgj, copy=True), np.array(coj, copy=True)
+                assert (cgj == coj).all(), f"{workload} {what}: {tagr} it{j}: counters {cgj} vs {coj}"
+                qo = o.queue_read(Q.EXTENSION)[:int(coj[Q.EXTENSION])]
+                g.wf_extend(); o.wf_extend(); g.finish()
+                sg, so = g.state_export(), o.state_export()
+                flip = np.zeros(sg.shape[1], bool)
+                flip[qo] = sg.view(np.uint32)[COL.HIT_I][qo] != so.view(np.uint32)[COL.HIT_I][qo]
+                fails = common.state_diff(sg, so, 0.0, 0.0, mask=~flip)
+                assert not fails, f"{workload} {what}: {tagr} it{j} after extend, beyond hit-index flips: " + "; ".join(fails[:4])
+                if flip.any():
+                    fr = np.nonzero(flip)[0]
+                    assert np.allclose(sg[COL.HIT_T][fr], so[COL.HIT_T][fr], rtol=1e-5, atol=1e-6), f"{workload} {what}: {tagr} it{j}: a flip that is not a tie in t"
+                    tied_.update(int(x) for x in fr)
+                    if oracle_follows_device:
+                        o.state_import(sg)
+                    else:
+                        g.state_import(so)
+                g.wf_shadow(); o.wf_shadow()
+                # (the main loop advanced BOTH cursors by the oracle's count of that iteration: ray_counts)
+                for c in (g, o):
+                    c.clear_queues(); c.finish(); c.pixel_index_update(npix, ray_counts[j])
+                cur_ = (cur_ + ray_counts[j]) % npix
+            return tied_, cur_
+
+        tied, cur = replay(False)
+        # the replay ends where the oracle stood (it is deterministic)
         fails = common.state_diff(o.state_export(), s1, 0.0, 0.0)
         assert not fails, f"{workload} {what}: the oracle's replay does not reproduce its own run: " + "; ".join(fails[:3])
         assert cur == cursor
+        rest = set(int(x) for x in bad_paths) - tied
+        shifted = set()
+        if rest:
+            assert tied, f"{workload} {what}: paths {sorted(rest)[:8]} differ from the oracle and the replay shows no hit-index tie at all"
+            tied2, cur2 = replay(True)
+            assert cur2 == cursor
+            so2 = o.state_export()
+            still = ((so2.view(np.uint32) != sg_main.view(np.uint32)) & ~skip[:, None]).any(axis=0)
+            if still.any():                               # diagnostics: which columns the device-following oracle and the device's main run disagree in
+                for x in np.nonzero(still)[0][:4]:
+                    cols = [c for c in range(64) if not skip[c] and sg_main.view(np.uint32)[c][x] != so2.view(np.uint32)[c][x]]
+                    print(f"[fork] path {x}: device main run vs oracle following the device's ties differ in " + ", ".join(f"{common.colname(c)}: {sg_main[c][x]!r} vs {so2[c][x]!r}" for c in cols))
+            assert not still.any(), (f"{workload} {what}: {int(still.sum())} paths of the device's main run are NOT what the oracle computes from the device's own tie choices "
+                                     f"(first: {np.nonzero(still)[0][:8]}; ties: {sorted(tied)[:8]}, in replay 2: {sorted(tied2)[:8]})")
+            shifted = rest - tied2                        # regenerated onto the neighbouring pixel behind a tie (or forked by a tie of their own on that new path: tied2)
+            tied |= (tied2 & rest)
+            for c in (g, o):                              # back to where the main loop continues: the oracle's own run
+                c.state_import(s1); c.pixel_index_reset(); c.pixel_index_update(npix, cursor)
+        shifted_total[0] += len(shifted)
+        explained.extend(sorted(tied))
+        last_shifted[0] = len(shifted)
 
     def checkpoint(what, upto):
         nonlocal forked
@@ -482,6 +494,7 @@ def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""
         cg, co = cnt
         for c in (g, o):
             c.pixel_index_update(npix, int(co[Q.RAYGEN]))
+        ray_counts[it] = int(co[Q.RAYGEN])
         cursor = (cursor + int(co[Q.RAYGEN])) % npix
         rays += int(co[Q.EXTENSION]) + int(co[Q.SHADOW]); ext_rays += int(co[Q.EXTENSION])
         if not (cg == co).all():
@@ -540,6 +553,50 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
     fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
     assert not fails, "; ".join(fails[:5])
     assert common.fb_close(a.read_pixels(0), b.read_pixels(0))
+    for g in ctx:
+        g.close()
+
+
+@pytest.mark.parametrize("workload,cap", [("kitchen", 28), ("kitchen", 12), ("conference", 28), ("egyptcat", 20), ("courtyard-1440p", 28)])
+def test_early_extension_start_is_bit_identical(workload, cap):
+    """Option `early_ext` (api.hip: EARLY EXTENSION START): the extension queue in two segments -- the paths whose material step the fused pass inlined, traced by
+    a launch of the persistent closest-hit kernel that starts behind `logic` alone, beside genRays and the material kernel; the regenerated paths and the paths of
+    the other BSDF types, traced by a second launch behind those two -- against the single launch over the whole queue.  Which launch traces a ray changes nothing
+    about the ray: two contexts free-run the workload at 1 M paths (diffuse-inline pass = ext order 3 on the kitchen; all-types pass = order 1's own
+    [regenerated | continuing] split on the conference scene and the courtyard; single material queue on egyptcat), counters after every iteration, the extension
+    queue as a set, the whole state after 3 and 12 iterations, the framebuffers.  cap = persistent waves per CU of the early launch."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    ctx = []
+    for e in (0, cap):
+        g = HipContext(n)
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); g.set_option("early_ext", e); driver.reset_renderer(g)
+        ctx.append(g)
+    a, b = ctx
+    assert a.get_option("early_ext") == 0 and b.get_option("early_ext") == cap and a.get_option("ext_order") == b.get_option("ext_order")
+    for it in range(12):
+        for g in (a, b):
+            g.wf_logic(False); g.wf_raygen(); g.wf_materials()
+        ca, cb = a.get_counters(), b.get_counters()
+        if it in (1, 7):                                   # the queue itself: the same set of paths (this read-back breaks the chain: this iteration runs as one launch)
+            a.finish()
+            ne = int(np.array(ca, copy=True)[Q.EXTENSION])
+            assert np.array_equal(np.sort(a.queue_read(Q.EXTENSION)[:ne]), np.sort(b.queue_read(Q.EXTENSION)[:ne])), f"{workload} it{it}: extension queues hold different paths"
+        for g in (a, b):
+            g.wf_extend(); g.wf_shadow(); g.clear_queues(); g.finish()
+        ca, cb = np.array(ca, copy=True), np.array(cb, copy=True)
+        assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
+        for g in (a, b):
+            g.pixel_index_update(npix, int(ca[Q.RAYGEN]))
+        if it == 2:
+            fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+            assert not fails, "after 3 iterations: " + "; ".join(fails[:5])
+    fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+    assert not fails, "; ".join(fails[:5])
+    pa, pb = a.read_pixels(0), b.read_pixels(0)
+    assert np.array_equal(pa[:, 3], pb[:, 3]) and common.fb_close(pa, pb)
     for g in ctx:
         g.close()
 
