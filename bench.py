@@ -145,7 +145,7 @@ def capture_key(args, ctx, p, C=1):
             "num_tasks": args.num_tasks // C, "extend_tree": args.extend_tree, "shadow_tree": args.shadow_tree,
             "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"),
             "fuse": int(args.fuse), "fuse_set": ctx.get_option("fuse_set_now"), "ext_order": ctx.get_option("ext_order"),
-            "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"), "regroup": ctx.get_option("regroup"), "early_ext": ctx.get_option("early_ext"),
+            "shadow_split": ctx.get_option("shadow_split"), "regen": ctx.get_option("regen"), "regroup": ctx.get_option("regroup"), "regen_prep": ctx.get_option("regen_prep"),
             # which BINARY ran: the shipped library or an A/B variant (FLX_HIP_LIB, e.g. a -DFLX_LAB build of the same sources), and its compile flags
             "library": os.path.basename(os.environ.get("FLX_HIP_LIB") or "libfluctus_hip.so"), "build_flags": " ".join(build.HIP_FLAGS),
             "source_hash": build.source_hash()}
@@ -199,7 +199,7 @@ def cpu_baseline(d, p, env, budget_s=12.0, force_kind=None):
             "sample": f"{what}; same scene/params, 65536 paths in flight, {iters} iterations after 16 warm-up, {dt:.1f} s"}
 
 
-def ref_gpu_baseline(ctx, d, p, args, settle):
+def ref_gpu_baseline(ctx, d, p, env, args, settle):
     """The reference's OWN wf_*.cl kernels on THIS GPU (untimed leg, rank 0 at N = 1; the product path is untouched): oracle/_ref/gfx950/fast/*.co =
     /root/reference/src/wf_*.cl compiled unmodified for gfx950 with the reference's own build flags (-cl-fast-relaxed-math, src/clcontext.cpp:145) and
     AMD's OpenCL built-in library (oracle/ref/Makefile, target gfx950), loaded by oracle/ref_gpu.py -- test infrastructure, imported here exactly like
@@ -207,8 +207,10 @@ def ref_gpu_baseline(ctx, d, p, args, settle):
       (a) `traversal`: the reference's traceExtension / traceShadow (src/wf_extrays.cl:5-36, src/wf_shadowrays.cl:6-38; NDRange = NUM_TASKS work-items,
           src/clcontext.cpp:815-850) on the SAME extension / shadow queues and path state as the product's steady state at --num-tasks, each alone on the
           machine, best of 3 -- beside the product's k_trace4r / k_shadow4 alone (serial schedule) on the same steady state;
-      (b) `whole_loop` (workloads without an environment map only: `logic` with USE_ENV_MAP samples an image and gfx950 has no image support): the
-          reference's complete runBenchmark iteration (src/tracer.cpp:433-439, one finishQueue per iteration) at its own wfBufferSize 2^20 and at
+      (b) `whole_loop`: the reference's complete runBenchmark iteration -- for a workload with an environment map with ONE builder-written piece in it: `logic`
+          with USE_ENV_MAP samples an image, gfx950 has no image instructions, so its read_imagef / get_image_dim come from oracle/ref/gfx950_image_standin.cl
+          (everything else of that kernel, and every other kernel, is AMD's compiler + built-in library on the reference's unmodified source;
+          `whole_loop_image_standin` says which case it is) -- the reference's complete runBenchmark iteration (src/tracer.cpp:433-439, one finishQueue per iteration) at its own wfBufferSize 2^20 and at
           --num-tasks -> Mrays/s, beside the product at the same sizes."""
     from fluctus_amd import device, driver
     from oracle import ref_gpu
@@ -263,13 +265,18 @@ def ref_gpu_baseline(ctx, d, p, args, settle):
     finally:
         ctx.set_option("overlap", args.overlap)
         ctx.counter_totals(reset=True)
-    # ---- (b) the reference's whole loop (no environment map: every kernel of it runs on gfx950)
-    if not int(p["useEnvMap"]):
+    # ---- (b) the reference's whole loop.  Without an environment map every kernel of it runs on gfx950 as AMD's compiler and built-in library made it; with one,
+    # `logic` is the image stand-in build (oracle/ref/gfx950_image_standin.cl: read_imagef / get_image_dim restated, everything else AMD's) -- labelled.
+    use_env = bool(int(p["useEnvMap"]))
+    if (not use_env) or ref_gpu.available_env("fast"):
         loops = {}
+        out["whole_loop_image_standin"] = use_env
         for size in sorted({1 << 20, n}):
             try:
                 r = ref_gpu.RefGpuContext(size, backend_name="hip", flavour="fast")      # (`logic` carries an image2d_t argument: module loader, null descriptor)
                 r.upload_scene(d); r.set_params(p)
+                if use_env:
+                    r.upload_envmap(env)
                 driver.reset_renderer(r)
                 for _ in range(settle):
                     driver.benchmark_iteration(r, npix)
@@ -280,7 +287,10 @@ def ref_gpu_baseline(ctx, d, p, args, settle):
                 dt = time.perf_counter() - t0
                 r.close()
                 g = device.HipContext(size)
-                g.upload_scene(d); g.set_params(p)
+                g.upload_scene(d)
+                if use_env:
+                    g.upload_envmap(env)
+                g.set_params(p)
                 driver.reset_renderer(g)
                 for _ in range(settle):
                     step_async(g)
@@ -301,7 +311,7 @@ def ref_gpu_baseline(ctx, d, p, args, settle):
         out["whole_loop"] = loops
     else:
         out["whole_loop"] = None
-        out["whole_loop_note"] = "logic with USE_ENV_MAP samples an image2d_t (read_imagef); gfx950 has no image support, so the reference's whole loop cannot run on this device for an env-map workload"
+        out["whole_loop_note"] = "logic with USE_ENV_MAP samples an image2d_t (read_imagef); gfx950 has no image support and the image stand-in builds (oracle/_ref/gfx950/fast/logic_v*_imgstandin.co) are absent"
     return out
 
 
@@ -327,7 +337,7 @@ def main():
     ap.add_argument("--refill-extend", type=int, default=-1, help="closest-hit traversal with persistent waves: refill when this many lanes are idle (0 = thread-per-ray kernel, -1 = library default)")
     ap.add_argument("--refill-shadow", type=int, default=-1, help="the same for the any-hit traversal")
     ap.add_argument("--regen", type=int, default=-1, help="in-kernel regeneration of terminating paths by the fused logic pass (option regen): 0 off (genRays kernel), 1 on, -1 = library default")
-    ap.add_argument("--early-ext", type=int, default=-1, help="early start of the closest-hit kernel on the queue segment of the paths the fused pass inlined (option early_ext): 0 off, n = on with that launch's grid capped at n waves per CU, -1 = library default")
+    ap.add_argument("--regen-prep", type=int, default=-1, help="prepared regeneration (option regen_prep): the seed-only half of genRays inside the fused RAW pass; 0 / 1, -1 = library default (1)")
     ap.add_argument("--regroup", type=int, default=-1, help="all-types fused pass with its material step sorted by BSDF type per block (option regroup): 0 / 1, -1 = what flx_upload_scene picks for the scene")
     ap.add_argument("--shadow-split", type=int, default=-1, help="tail splitting of the any-hit kernel: node-visit budget of the pass over the queue | budget of a second pass << 8; 0 = off, -1 = library default")
     ap.add_argument("--ctx-per-gpu", type=int, default=1, help="independent wavefronts per GPU (pixel-interleaved sub-partitions, paths split evenly)")
@@ -385,9 +395,9 @@ def main():
             c_.set_option("shadow_split", args.shadow_split)
         if args.regen >= 0:
             c_.set_option("regen", args.regen)
-        if args.early_ext >= 0:
-            c_.set_option("early_ext", args.early_ext)
         c_.set_option("regroup", args.regroup)
+        if args.regen_prep >= 0:
+            c_.set_option("regen_prep", args.regen_prep)
         c_.upload_scene(d)
         if args.fuse_set:
             c_.set_option("fuse_set", args.fuse_set)          # after the upload, which picks one for the scene
@@ -685,7 +695,9 @@ def main():
     any_order = 1 if (int(p["useEnvMap"]) and not int(p["useAreaLight"])) else 0
     k_ext = "k_trace4r<false, 0>" if ctx.get_option("refill_extend") else "k_extend4<false>"
     k_sh = None if ctx.get_option("shadow_split") else (f"k_trace4r<true, {any_order}>" if ctx.get_option("refill_shadow") else f"k_shadow4<false, {any_order}>")
-    k_lg = (f"k_logic<{ctx.get_option('fuse_set_now')}, {'true' if ctx.get_option('refill_extend') else 'false'}>") if args.fuse else "k_logic<0, false>"
+    _raw = bool(ctx.get_option("refill_extend")) and args.extend_tree == 4
+    _rg = _raw and ctx.get_option("fuse_set_now") == 31 and bool(ctx.get_option("regroup")) and (args.num_tasks // C) % 256 == 0
+    k_lg = (f"k_logic<{ctx.get_option('fuse_set_now')}, {'true' if _raw else 'false'}, {'true' if _rg else 'false'}>") if args.fuse else "k_logic<0, false, false>"
 
     def valu_block(insts, lanes, secs, kname=None):
         if not insts or not secs:
@@ -775,7 +787,7 @@ def main():
                                    ("egyptcat.obj (REAL reference asset, reference benchmark protocol: 1024x1024, start-up parameters, single material queue)" if args.workload == "egyptcat" else args.workload + "-proc"),
                        "width": args.width, "height": args.height, "max_bounces": int(p["maxBounces"]), "triangles": int(d.tris.size),
                        "bvh": WORKLOADS[args.workload][3], "bvh_nodes": int(d.nodes.size), "num_tasks_per_gpu": args.num_tasks, "num_tasks_whole_job": args.num_tasks * world, "scaling_mode": ("weak: --num-tasks paths in flight per rank" if args.scaling == "weak" else f"strong: {num_tasks_total} paths in flight over the whole job, {args.num_tasks} per rank"), "wavefronts_per_gpu": C, "fused_logic_materials": bool(args.fuse), "fused_bsdf_set": ctx.get_option("fuse_set_now") if args.fuse else 0, "ext_order": ctx.get_option("ext_order") if args.fuse else 0,
-                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"), "early_ext": ctx.get_option("early_ext"), "regroup": ctx.get_option("regroup"),
+                       "refill_extend": ctx.get_option("refill_extend"), "refill_shadow": ctx.get_option("refill_shadow"), "shadow_split": ctx.get_option("shadow_split"), "overlap": ctx.get_option("overlap"), "regroup": ctx.get_option("regroup"),
                        "parallelism": f"pixel-interleaved x{world}, no collective in the timed region"},
             "rays": {"primary": prim, "extension": ext, "shadow": sh,
                      "reference_style_total_Mrays_s": (prim + ext + sh) / elapsed / 1e6},
@@ -792,7 +804,7 @@ def main():
             if native_err:
                 line["gather_native_error"] = native_err
         if world == 1 and C == 1 and not args.no_ref_gpu_baseline:
-            line["ref_gpu_baseline"] = ref_gpu_baseline(ctx, d, p, args, settle)
+            line["ref_gpu_baseline"] = ref_gpu_baseline(ctx, d, p, env, args, settle)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(d, p, env)
             if line["cpu_baseline"]["kind"] == "reference":      # the oracle port beside it (order-preserving appends instead of per-path atomics)

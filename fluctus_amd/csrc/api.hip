@@ -21,7 +21,7 @@ void launch_extend4(hipStream_t, const State &, const Queues &, const Scene &, c
 void launch_shadow4(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, unsigned long long *);
 void launch_shadow4_split(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t *, uint32_t, uint4 *, uint32_t, uint4 *, uint32_t, int, int, uint32_t);
 uint32_t shadow_split_lists(); uint32_t shadow_split_count_words();
-void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *, uint32_t, uint32_t, int);
+void launch_extend4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_shadow4r(hipStream_t, const State &, const Queues &, const Scene &, const flx_render_params &, uint32_t *, uint32_t, int, uint32_t *);
 void launch_logic(hipStream_t, const State &, const Queues &, const Scene &, const Frame &, const flx_render_params &, uint8_t *, uint32_t *, uint32_t *, int, int, int, int, int,
                   unsigned long long *, uint32_t, int, int, uint32_t *, int);
@@ -34,7 +34,7 @@ void launch_materials_after_fused(hipStream_t, const State &, const Queues &, co
 uint32_t fused_queue_mask(int);
 uint32_t logic_aux_stride(uint32_t);
 void launch_reset(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &);
-void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &, int);
+void launch_raygen(hipStream_t, const State &, const Queues &, const Frame &, const flx_render_params &, int, int);
 void launch_postprocess(hipStream_t, const Frame &, const flx_render_params &);
 void launch_state_export(hipStream_t, const State &, float *, float);
 void launch_state_import(hipStream_t, const State &, const float *);
@@ -74,17 +74,6 @@ struct flx_ctx {
     int overlap = 2;                            // 0 serial | 1 shadow || extension | 2 shadow starts right after logic (the EFFECTIVE schedule)
     int overlapOpt = -1;                        // option "overlap": -1 = the default (pickSchedule), else as set
     uint32_t *spill2 = nullptr;
-    // EARLY EXTENSION START (round 6, option "early_ext").  In the steady chain logic -> genRays -> materials -> extension the persistent closest-hit kernel used to
-    // start behind genRays and the material kernel of the non-inlined BSDF types -- two short kernels bound by isolated 16-byte stores (0.8 ms of a 4.9 ms kitchen
-    // step at 16 M paths, profiles/r05_kitchen_timeline.txt) -- although most of its rays exist the moment the fused pass ends: the continuing paths whose material
-    // step the pass inlined.  With early_ext on, the fused scatter lays the extension queue out in two segments (logic.hip, ext order 3: A = those paths, B = the
-    // regenerated paths + the paths of the other BSDF types; with the all-types pass the layout of order 1 already is [B | A]), flx_wf_extend launches the kernel
-    // on segment A on a third stream that waits for `logic` alone, and on segment B on the main stream behind genRays + the material kernel; the main stream then
-    // joins.  A ray's arithmetic does not depend on which launch traces it (tests: ..._bit_identical_to_thread_per_ray, the launch-chain tests); the queue holds the
-    // same set.  earlySeg is what the last fused chain laid out; it is used only if flx_wf_extend is the very next call (phase PH_CHAIN -> PH_CHAIN_EXT).
-    hipStream_t stream3 = nullptr; hipEvent_t evSegA = nullptr; uint32_t *spill3 = nullptr;
-    int earlyExt = 0;                           // option "early_ext": 0 off | n > 0: on, segment A's persistent grid capped at n waves per CU (>= 28: no cap)
-    struct { bool valid; uint32_t aBegin, aLen, bBegin, bLen; } earlySeg = {false, 0, 0, 0, 0};
     // logic + material kernels as one pass (logic.hip: k_logic<FUSED>).  flx_wf_logic is DEFERRED while `fuse` is on: it is
     // launched by the next call -- fused with the material kernels when that call is flx_wf_materials (a flx_wf_raygen between
     // the two is deferred along and launched right after), as the plain kernel when it is anything else.  Every entry point
@@ -110,7 +99,7 @@ struct flx_ctx {
     // in-kernel regeneration of the fused RAW pass (logic.hip: REGEN): look-back status words (one per wave, epoch-stamped: never reset), launch counter,
     // device error flag (a look-back that gave up), option "regen" (1: on where the pass allows it), and whether the LAST fused pass regenerated its
     // terminating paths itself -- then the genRays of the chain is not launched (flx_wf_materials)
-    unsigned long long *lookback = nullptr; uint32_t logicEpoch = 0; uint32_t *logicError = nullptr; int regenOpt = 0; bool regenDone = false; bool regenUsed = false;      // (off by default: profiles/r05_regen_ab.txt -- the look-back costs more than genRays)
+    unsigned long long *lookback = nullptr; uint32_t logicEpoch = 0; uint32_t *logicError = nullptr; int regenOpt = 0; bool regenDone = false; bool regenUsed = false; int prepOpt = 1; bool prepDone = false;      // (off by default: profiles/r05_regen_ab.txt -- the look-back costs more than genRays)
     // trace aux
     uint32_t *spill = nullptr;
     unsigned long long *stats = nullptr;   // device, 16 counters
@@ -137,7 +126,7 @@ struct flx_ctx {
     // fused logic pass of the next iteration (the steady state: nothing else touches hit records between the extension kernel and logic),
     // or by k_materialise as soon as an entry point that could observe a hit record runs (transition(): commitRaw).
     bool rawHits = false;
-    bool cursorDirty[3] = {false, false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
+    bool cursorDirty[2] = {false, false};       // block cursors of the persistent kernels (closest hit, any hit) used since they were last zeroed
 
     uint32_t wideInfo[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // flx_scene_info
     bool wideOK = false;        // the uploaded scene has a wide tree whose exactness conditions hold (nested boxes)
@@ -192,7 +181,7 @@ struct ScopedTimer {
     ScopedTimer(flx_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream)
     {
         on = c->profile == 1 || (c->profile == 2 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW)) || (c->profile == 3 && k == FLX_K_EXTEND) ||
-             (c->profile == 4 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW || k == FLX_K_LOGIC || k == FLX_K_LOGIC_FUSED)) || (c->profile >= 2 && k == FLX_K_EXTEND_B);
+             (c->profile == 4 && (k == FLX_K_EXTEND || k == FLX_K_SHADOW || k == FLX_K_LOGIC || k == FLX_K_LOGIC_FUSED));
         if (on) { a = getEvent(c); b = getEvent(c); (void)hipEventRecord(a, s); }
     }
     ~ScopedTimer() { if (on) { (void)hipEventRecord(b, s); c->events.push_back({k, a, b}); } }
@@ -320,7 +309,6 @@ int flx_create(int device, uint32_t num_tasks, flx_ctx **out)
         if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, pMain)) != hipSuccess) return fail("hipStreamCreate", e);
         if ((e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, pSecond)) != hipSuccess) return fail("hipStreamCreate", e);
     }
-    if ((e = hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSegA, hipEventDisableTiming)) != hipSuccess) return fail("hipStreamCreate(3)", e);
     if ((e = hipEventCreateWithFlags(&c->evPreExt, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evShadow, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evPostLogic, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     const size_t N = num_tasks;
@@ -400,8 +388,6 @@ int flx_destroy(flx_ctx *c)
     for (auto &ev : c->events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->stream3) { (void)hipStreamSynchronize(c->stream3); (void)hipStreamDestroy(c->stream3); }
-    if (c->evSegA) (void)hipEventDestroy(c->evSegA);
     if (c->evPreExt) (void)hipEventDestroy(c->evPreExt);
     if (c->evShadow) (void)hipEventDestroy(c->evShadow);
     if (c->evPostLogic) (void)hipEventDestroy(c->evPostLogic);
@@ -481,10 +467,12 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         // all): courtyard (65 % diffuse) 2158 -> 2258 and 2221 -> 2274 Mrays/s at 1440p, 2088 -> 2167 and 2189 -> 2200 at 2160p -- a third of
         // its paths took the second trip -- kitchen (96 %) 5297 -> 5152 and 5485 -> 5198.  Hence all types below 3/4 diffuse (round 2: 1/2).
         c->fuseSet = (areaAll > 0.0 && areaDiffuse < 0.75 * areaAll) ? 31 : 1;
-        // ... and whether the all-types pass sorts its material step by BSDF type inside each block (logic.hip: LOGIC_REGROUP, k_logic<31, true, true>: 119 VGPRs
-        // against 92).  Same box, 16 M paths (profiles/r05_regroup_ab.txt, r06_regroup_ab.txt): courtyard (65 % diffuse) step +3.8 %, egyptcat (single material queue,
-        // mostly diffuse) +3.4 %, conference (13 % diffuse, three types of similar weight) -0.5 %: on where ONE type holds at least half of the surface area.
-        c->regroupAuto = (areaAll > 0.0 && areaDiffuse >= 0.5 * areaAll) ? 1 : 0;
+        // ... and whether the all-types pass sorts its material step by BSDF type inside each block (logic.hip: LOGIC_REGROUP, k_logic<31, true, true>).  Round 5's
+        // build of it needed 119 VGPRs (4 waves per SIMD) and paid only where one type dominates (profiles/r05_regroup_ab.txt); as a template instance of its own,
+        // compiled for 5 blocks per CU, it fits 96 VGPRs without scratch, and the same-box A/B at 16 M paths reads (profiles/r06_regroup_ab.txt, off -> on, Mrays/s):
+        // conference 5392 -> 5678 and 5376 -> 5654 (+5.2 %), courtyard-1440p 2512 -> 2503 and 2483 -> 2491, egyptcat 6079 -> 6074 and 6009 -> 6042 (both +-0.5 %: the
+        // box's spread).  On whenever the all-types pass runs; option "regroup" overrides.
+        c->regroupAuto = 1;
         c->regroup = c->regroupOpt >= 0 ? c->regroupOpt : c->regroupAuto;
         // ... and the order in which the fused pass lists the continuing paths in the extension queue (logic.hip: k_queue_scatter): one
         // segment per material queue, as the separate kernels append them, or all of them by path id.  Same-box A/B, Mrays/s segments ->
@@ -615,7 +603,6 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
     // so a failed upload leaves the context on its old scene instead of on dangling pointers.
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
-    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     std::vector<void *> fresh, freshSpill;
     auto bail = [&]() { freeAll(fresh); freeAll(freshSpill); return 1; };
     BNode *dB; TriRec *dT; ShadeRec *dS; flx_triangle *dTri; flx_material *dM; flx_texdesc *dD; uint8_t *dX; flxw::WNode *dW; float4 *dL;
@@ -623,10 +610,10 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
         dalloc(c, fresh, &dTri, ntris) || dalloc(c, fresh, &dM, nmat) || dalloc(c, fresh, &dD, ntex) || dalloc(c, fresh, &dX, texbytes + 4) ||
         dalloc(c, fresh, &dW, wide.nodes.size()) || dalloc(c, fresh, &dL, wide.leafdata.size() + 4))
         return bail();
-    uint32_t *sp1 = c->spill, *sp2 = c->spill2, *sp3 = c->spill3;
+    uint32_t *sp1 = c->spill, *sp2 = c->spill2;
     const size_t lanes = ((size_t)c->numTasks + 255) / 256 * 256 + 1024;
     const bool newSpill = spillLevels > c->spillLevels || !c->spill;
-    if (newSpill && (dalloc(c, freshSpill, &sp1, lanes * spillLevels) || dalloc(c, freshSpill, &sp2, lanes * spillLevels) || dalloc(c, freshSpill, &sp3, lanes * spillLevels))) return bail();
+    if (newSpill && (dalloc(c, freshSpill, &sp1, lanes * spillLevels) || dalloc(c, freshSpill, &sp2, lanes * spillLevels))) return bail();
 #define UPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(); } } while (0)
     UPCHK(hipMemcpy(dB, bnodes.data(), bnodes.size() * sizeof(BNode), hipMemcpyHostToDevice));
     UPCHK(hipMemcpy(dT, trirecs.data(), trirecs.size() * sizeof(TriRec), hipMemcpyHostToDevice));
@@ -640,7 +627,7 @@ int flx_upload_scene(flx_ctx *c, const void *trisv, size_t ntris, const uint32_t
 #undef UPCHK
     freeAll(c->sceneAllocs);
     c->sceneAllocs.swap(fresh);
-    if (newSpill) { freeAll(c->spillAllocs); c->spillAllocs.swap(freshSpill); c->spill = sp1; c->spill2 = sp2; c->spill3 = sp3; c->spillLevels = spillLevels; }
+    if (newSpill) { freeAll(c->spillAllocs); c->spillAllocs.swap(freshSpill); c->spill = sp1; c->spill2 = sp2; c->spillLevels = spillLevels; }
     c->sc.bnodes = dB; c->sc.trirecs = dT; c->sc.shade = dS; c->sc.tris = dTri; c->sc.materials = dM; c->sc.texdesc = dD; c->sc.texdata = dX;
     c->sc.rootRef = 0;
     c->sc.wnodes = dW; c->sc.wleaf = dL; c->sc.wrootRef = wide.rootRef;
@@ -725,11 +712,11 @@ int flx_wf_reset(flx_ctx *c) { READY(c, CALL_OBSERVE); flushExt(c); c->raygenQue
 // a base that counts the first append twice (ext_len) while extPend |= bit stays idempotent: flush first, so that every
 // call order the reference's atomic append accepts (src/utils.cl:328-358) works here too.
 static void flushExtIfPending(flx_ctx *c, uint32_t bits) { if (c->qs.extPend & bits) flushExt(c); }
-static int runRaygen(flx_ctx *c, int appendExt = 1, bool alreadyDone = false)
+static int runRaygen(flx_ctx *c, int appendExt = 1, bool alreadyDone = false, bool prepared = false)
 {
     flushExtIfPending(c, 1u << FLX_Q_RAYGEN);
     // alreadyDone: the fused RAW pass of this chain regenerated the paths (and appended them) itself: only the bookkeeping of the call is left
-    if (!alreadyDone) { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params, appendExt); }
+    if (!alreadyDone) { ScopedTimer t(c, FLX_K_RAYGEN); launch_raygen(c->stream, c->st, c->qs, c->fr, c->params, appendExt, prepared ? 1 : 0); }
     c->qs.extPend |= 1u << FLX_Q_RAYGEN;
     if (c->eagerBump) flushExt(c);
     LAUNCHED(c);
@@ -750,15 +737,7 @@ static int materialise(flx_ctx *c)
 // (continuing paths by id, genRays appends its own block whenever it is called) otherwise
 // ... and a raygen queue that was EMPTY before this logic pass: the merged list is ranked from the scan offsets, which start at the raygen counter's old
 // value, while genRays with appendExt 0 would never fill the slots in front (flx_wf_reset leaves numTasks entries there without a clear: round 4's advisor)
-static bool earlyExtPossible(const flx_ctx *c) { return c->earlyExt > 0 && c->overlap == 2 && c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn; }
-static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst)
-{
-    if (!fused) return 0;
-    if (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) return 1;
-    // order 3 = order 2 in two segments (EARLY EXTENSION START); only worth it when some BSDF type is NOT inlined (else order 1's [regenerated | continuing] is the split)
-    if (c->extOrder == 2 && earlyExtPossible(c)) return 3;
-    return c->extOrder;
-}
+static int extOrderFor(const flx_ctx *c, int fused, int raygenFirst) { return !fused ? 0 : (c->extOrder == 2 && (!raygenFirst || !c->raygenQueueEmpty)) ? 1 : c->extOrder; }
 // the BSDF set the fused pass inlines NOW: the scene's choice (flx_upload_scene / option "fuse_set") with separate material queues; with a single material
 // queue (WF_SINGLE_MAT_QUEUE: every BSDF type sits in the diffuse list) only a pass that inlines every type can serve it, so it is the all-types pass
 // whatever the scene's choice says -- round 5: egyptcat under the reference's benchmark protocol ran the separate logic + k_material<31> + k_materialise
@@ -770,7 +749,6 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     // kernel and a chain without genRays get them committed first
     // ... and only when the pass covers EVERY path: with `first` set, logic stops at min(numTasks, pixels) (src/wf_logic.cl:45-48) and the paths
     // beyond would keep their RAW records (found by tests/test_gpu_fuzz.py, round 4)
-    c->earlySeg.valid = false;
     const int raw = (c->rawHits && fused != 0 && raygenFirst && !first) ? 1 : 0;
     if (!raw && materialise(c)) return 1;
     c->rawHits = false;
@@ -785,9 +763,13 @@ static int runLogic(flx_ctx *c, int first, int fused, int raygenFirst)
     const int regen = (raw && c->regenOpt && c->lookback && logic_can_regenerate() && c->raygenQueueEmpty && c->fr.localPixels > 0 && c->numTasks <= (1u << 26)) ? 1 : 0;
     c->regenDone = regen != 0;
     if (regen) c->regenUsed = true;
+    // PREPARED REGENERATION (logic.hip; option "regen_prep", default on): the seed-only half of genRays inside the RAW pass, the pixel-dependent half in the
+    // k_raygen that follows.  Same conditions as the in-kernel regeneration (every entry of the raygen queue is a path this pass terminated), minus the look-back.
+    const int prep = (raw && !regen && c->prepOpt && c->raygenQueueEmpty && c->fr.localPixels > 0) ? 1 : 0;
+    c->prepDone = prep != 0;
     if (++c->logicEpoch == 0u) c->logicEpoch = 1u;     // (epoch 0 = the zero-filled words of a fresh context)
     { ScopedTimer t(c, fused ? FLX_K_LOGIC_FUSED : FLX_K_LOGIC); launch_logic(c->stream, c->st, c->qs, c->sc, c->fr, c->params, c->member, c->blockCounts, c->blockOffsets, first, fused, raygenFirst, order, raw,
-                                                                                c->lookback, c->logicEpoch, regen, (order == 2 || order == 3) ? 0 : 1, c->logicError, c->regroup); }
+                                                                                c->lookback, c->logicEpoch, regen ? 1 : (prep ? 2 : 0), order == 2 ? 0 : 1, c->logicError, c->regroup); }
     LAUNCHED(c);
     c->matQueuesEmpty = false; c->raygenQueueEmpty = false;
     if (c->overlap == 2) HIPCHK(c, hipEventRecord(c->evPostLogic, c->stream));
@@ -828,29 +810,12 @@ int flx_wf_extend(flx_ctx *c)
     // packet in front of the extension kernel)
     if (c->overlap && !(c->overlap == 2 && chainIntact)) HIPCHK(c, hipEventRecord(c->evPreExt, c->stream));
     if (c->profile == 1 || c->profile == 2) { if (c->spanStart) c->eventPool.push_back(c->spanStart); c->spanStart = getEvent(c); (void)hipEventRecord(c->spanStart, c->stream); }
-    if (chainIntact && c->earlySeg.valid && earlyExtPossible(c)) {
-        // EARLY EXTENSION START (flx_ctx::earlyExt): segment A on the third stream, behind `logic` alone; segment B here, behind genRays + the material kernel; join
-        c->earlySeg.valid = false;
-        uint32_t *curA = c->qs.cursors, *curB = c->qs.cursors + 16 * FLX_CURSOR_STRIDE;
-        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->evPostLogic, 0));
-        if (c->cursorDirty[0]) HIPCHK(c, hipMemsetAsync(curA, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream3));
-        { ScopedTimer t(c, FLX_K_EXTEND, c->stream3);
-          launch_extend4r(c->stream3, c->st, c->qs, c->sc, c->params, c->spill3, (uint32_t)c->numCUs, c->refillExt, curA, c->earlySeg.aBegin, c->earlySeg.aLen, c->earlyExt); }
-        HIPCHK(c, hipEventRecord(c->evSegA, c->stream3));
-        if (c->cursorDirty[2]) HIPCHK(c, hipMemsetAsync(curB, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream));
-        { ScopedTimer t(c, FLX_K_EXTEND_B);
-          launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, curB, c->earlySeg.bBegin, c->earlySeg.bLen, 0); }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->evSegA, 0));
-        c->cursorDirty[0] = c->cursorDirty[2] = true; c->rawHits = true;
-        LAUNCHED(c);
-        return 0;
-    }
     {
         ScopedTimer t(c, FLX_K_EXTEND);
         if (c->extendTree == 4 && c->wideOK && c->refillExt > 0 && !c->statsOn) {
             uint32_t *cur = c->qs.cursors;
             if (c->cursorDirty[0]) HIPCHK(c, hipMemsetAsync(cur, 0, 4 * 8 * FLX_CURSOR_STRIDE, c->stream));      // (no k_end_iteration since the last launch)
-            launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, cur, 0u, 0u, 0);
+            launch_extend4r(c->stream, c->st, c->qs, c->sc, c->params, c->spill, (uint32_t)c->numCUs, c->refillExt, cur);
             c->cursorDirty[0] = true; c->rawHits = true;
         }
         else if (c->extendTree == 4 && c->wideOK) launch_extend4(c->stream, c->st, c->qs, c->sc, c->params, c->spill, c->statsOn ? c->stats : nullptr);
@@ -947,13 +912,8 @@ int flx_wf_materials(flx_ctx *c)
         const int fuseNow = fuseSetNow(c);
         const int order = extOrderFor(c, fuseNow, withRaygen);
         if (runLogic(c, c->pendFirst, fuseNow, withRaygen)) return 1;
-        if (withRaygen && runRaygen(c, (order == 2 || order == 3) ? 0 : 1, c->regenDone)) return 1;
-        c->regenDone = false;
-        {   // which two segments the extension queue now consists of (EARLY EXTENSION START), as queue-counter masks
-            const uint32_t mats = materialBits(c), inl = fused_queue_mask(fuseNow) & mats, rg = 1u << FLX_Q_RAYGEN;
-            if (withRaygen && order == 3) c->earlySeg = {true, 0u, inl, inl, rg | (mats & ~inl)};                     // [A: inlined | B: regenerated + the other types]
-            else if (withRaygen && order == 1 && inl == mats && earlyExtPossible(c)) c->earlySeg = {true, rg, mats, 0u, rg};   // [B: regenerated (genRays appended them) | A: every continuing path]
-        }
+        if (withRaygen && runRaygen(c, order == 2 ? 0 : 1, c->regenDone, c->prepDone)) return 1;
+        c->regenDone = false; c->prepDone = false;
         // BSDF types the fused pass does not inline went to their queues as usual: the material kernel for those
         { ScopedTimer t(c, FLX_K_MATERIALS); launch_materials_after_fused(c->stream, c->st, c->qs, c->sc, fused_queue_mask(fuseNow), order); }
         LAUNCHED(c);
@@ -999,9 +959,9 @@ int flx_clear_queues(flx_ctx *c)
     c->qs.extPend = 0; c->matQueuesEmpty = true; c->raygenQueueEmpty = true;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(c->qs.counters, 0, 32, c->stream));
-    if (c->cursorDirty[0] || c->cursorDirty[1] || c->cursorDirty[2]) {       // the block cursors of the persistent traversal kernels go with the counters
+    if (c->cursorDirty[0] || c->cursorDirty[1]) {       // the block cursors of the persistent traversal kernels go with the counters
         HIPCHK(c, hipMemsetAsync(c->qs.cursors, 0, 4 * FLX_NUM_BLOCK_CURSORS * FLX_CURSOR_STRIDE, c->stream));
-        c->cursorDirty[0] = c->cursorDirty[1] = c->cursorDirty[2] = false;
+        c->cursorDirty[0] = c->cursorDirty[1] = false;
     }
     return 0;
 }
@@ -1070,7 +1030,7 @@ int flx_end_iteration_async(flx_ctx *c)
 {
     READY(c, CALL_NEUTRAL);
     launch_end_iteration(c->stream, c->qs.counters, c->totals, c->fr.currPixelIdx, c->fr.localPixels, c->qs.extPend, c->qs.cursors);
-    c->cursorDirty[0] = c->cursorDirty[1] = c->cursorDirty[2] = false;      // (k_end_iteration zeroes the block cursors with the counters)
+    c->cursorDirty[0] = c->cursorDirty[1] = false;      // (k_end_iteration zeroes the block cursors with the counters)
     c->qs.extPend = 0;
     c->matQueuesEmpty = true; c->raygenQueueEmpty = true;      // it clears the queue counters
     LAUNCHED(c);
@@ -1475,7 +1435,7 @@ int flx_set_option(flx_ctx *c, const char *name, int value)
     if (name && strcmp(name, "fuse") == 0 && (value == 0 || value == 1)) { c->fuse = value; return 0; }
     if (name && strcmp(name, "ext_order") == 0 && value >= 0 && value <= 2) { c->extOrder = value; return 0; }
     if (name && strcmp(name, "regen") == 0 && (value == 0 || value == 1)) { if (value && optionBuffers(c, false, true)) return 1; c->regenOpt = value; return 0; }
-    if (name && strcmp(name, "early_ext") == 0 && value >= 0 && value <= 64) { ENTER(c, CALL_OBSERVE); c->earlyExt = value; return 0; }
+    if (name && strcmp(name, "regen_prep") == 0 && (value == 0 || value == 1)) { c->prepOpt = value; return 0; }
     if (name && strcmp(name, "regroup") == 0 && value >= -1 && value <= 1) { c->regroupOpt = value; c->regroup = value >= 0 ? value : c->regroupAuto; return 0; }
     if (name && strcmp(name, "fuse_set") == 0 && (value == 1 || value == 31)) { c->fuseSet = value; return 0; }
     if (name && strcmp(name, "overlap") == 0 && value >= -1 && value <= 2) { ENTER(c, CALL_OBSERVE); c->overlapOpt = value; pickSchedule(c); return 0; }
@@ -1507,7 +1467,7 @@ int flx_get_option(flx_ctx *c, const char *name, int *value)
     NEED(c, name && value, "flx_get_option: null");
     const struct { const char *n; int v; } tab[] = {
         {"xcd_remap", c->xcdRemap}, {"fuse", c->fuse}, {"overlap", c->overlap}, {"shadow_tree", c->shadowTree}, {"extend_tree", c->extendTree},
-        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"regroup", c->regroup}, {"early_ext", c->earlyExt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(fuseSetNow(c))}, {"fuse_set_now", fuseSetNow(c)}};
+        {"denoiser", c->denoiser}, {"eager_bump", c->eagerBump}, {"node_layout", c->nodeLayout}, {"fuse_set", c->fuseSet}, {"ext_order", c->extOrder}, {"regen", c->regenOpt}, {"regroup", c->regroup}, {"regen_prep", c->prepOpt}, {"refill_extend", c->refillExt}, {"refill_shadow", c->refillShadow}, {"shadow_split", c->shadowSplit}, {"fused_queue_mask", (int)fused_queue_mask(fuseSetNow(c))}, {"fuse_set_now", fuseSetNow(c)}};
     for (const auto &t : tab) if (strcmp(name, t.n) == 0) { *value = t.v; return 0; }
     if (strcmp(name, "phase") == 0) { *value = phaseCode(c); return 0; }
     c->err = std::string("flx_get_option: unknown option ") + name;

@@ -43,13 +43,12 @@ struct State {
     uint32_t numTasks;
 };
 
-// Block cursors of the persistent traversal kernels (trace4r.hip): one per XCD and kernel, [0..7] closest hit (whole queue, or its early segment: api.hip EARLY EXTENSION START),
-// [8..15] any hit, [16..23] closest hit, the segment traced behind genRays + the material kernel, FLX_CURSOR_STRIDE
+// Block cursors of the persistent traversal kernels (trace4r.hip): one per XCD and kernel, [0..7] closest hit, [8..15] any hit, FLX_CURSOR_STRIDE
 // words apart (every cursor is a hot atomic: each gets a cache line and L2 channel of its own).  A wave takes its next 64-ray block from the list of
 // its own XCD (blocks x, x + 8, x + 16, ...) and from the next XCD's list when its own is exhausted.  A persistent launch needs them at zero:
 // k_end_iteration zeroes them with the counters, flx_clear_queues does when a launch used them since (flx_ctx::cursorDirty), and the
 // launch sites (flx_wf_extend / flx_wf_shadow) zero them first whenever cursorDirty says neither happened in between.
-#define FLX_NUM_BLOCK_CURSORS 24
+#define FLX_NUM_BLOCK_CURSORS 16
 #define FLX_CURSOR_STRIDE 64
 
 struct Queues {

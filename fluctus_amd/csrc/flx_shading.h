@@ -159,14 +159,24 @@ __device__ __forceinline__ float env_map_pdf(const Scene &sc, f3 direction)
 
 // ---- camera ray of a (re)generated path (reference: genRays, src/wf_raygen.cl:22-66): jittered pixel position, pinhole direction, thin-lens origin.
 // Shared by k_raygen (misc.hip) and the fused logic pass's in-kernel regeneration (logic.hip).  localIdx: the rank's local pixel (cursor + queue index).
-__device__ __forceinline__ void camera_ray(const Frame &fr, const flx_render_params &p, uint32_t localIdx, uint32_t *seedp, f3 *orig, f3 *dir)
+// In three parts, because only ONE of them needs the pixel: the jitter (two draws) and the thin-lens origin (two more draws) are functions of the path's seed
+// alone, the direction needs the pixel = cursor + index in the raygen queue.  PREPARED REGENERATION (logic.hip / misc.hip) computes the first two in the fused
+// logic pass, where the terminating lane's origin / throughput + seed records ride on full-line stores, and leaves genRays the direction and the pixel.
+__device__ __forceinline__ f3 camera_lens_origin(const flx_render_params &p, uint32_t *seedp)      // draws 3 and 4: uniformSampleDisk, src/utils.cl:75-80
 {
-    uint32_t seed = *seedp;
+    const float sqrt_r = sqrtf(rand01(seedp));
+    const float th = FLX_2PI * rand01(seedp);
+    float sn, cs; sincosf_(th, &sn, &cs);
+    const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
+    return V(p.camera.pos) + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
+}
+__device__ __forceinline__ f3 camera_direction(const Frame &fr, const flx_render_params &p, uint32_t localIdx, float jx, float jy, f3 lensOrig)
+{
     const uint32_t pixelIdx = localIdx * fr.nranks + fr.rank;
     float x = (float)(pixelIdx % p.width);
     float y = (float)(pixelIdx / p.width);
-    x += rand01(&seed);
-    y += rand01(&seed);
+    x += jx;
+    y += jy;
     float NDCx = x / (float)p.width;
     float NDCy = y / (float)p.height;
     float SCRx = 2.0f * NDCx - 1.0f;
@@ -179,13 +189,16 @@ __device__ __forceinline__ void camera_ray(const Frame &fr, const flx_render_par
     f3 rayTarget = rayOrig + V(p.camera.right) * SCRx + V(p.camera.up) * SCRy + V(p.camera.dir);
     f3 rayDirection = normalize(rayTarget - rayOrig);
     const f3 fp = V(p.camera.pos) + rayDirection * p.camera.focalDist;
-    const float sqrt_r = sqrtf(rand01(&seed));                 // uniformSampleDisk, src/utils.cl:75-80
-    const float th = FLX_2PI * rand01(&seed);
-    float sn, cs; sincosf_(th, &sn, &cs);
-    const f2 rnd = mk2(sqrt_r * cs, sqrt_r * sn);
-    rayOrig = rayOrig + p.worldRadius * p.camera.apertureSize * (V(p.camera.right) * rnd.x + V(p.camera.up) * rnd.y);
-    rayDirection = normalize(fp - rayOrig);
-    *seedp = seed; *orig = rayOrig; *dir = rayDirection;
+    return normalize(fp - lensOrig);
+}
+__device__ __forceinline__ void camera_ray(const Frame &fr, const flx_render_params &p, uint32_t localIdx, uint32_t *seedp, f3 *orig, f3 *dir)
+{
+    uint32_t seed = *seedp;
+    const float jx = rand01(&seed);
+    const float jy = rand01(&seed);
+    const f3 lens = camera_lens_origin(p, &seed);
+    *dir = camera_direction(fr, p, localIdx, jx, jy, lens);
+    *seedp = seed; *orig = lens;
 }
 
 } // namespace flxd

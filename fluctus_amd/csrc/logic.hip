@@ -65,12 +65,13 @@ __host__ __device__ constexpr bool fuse_inlines_list(int fuse, uint32_t ml)     
 // (20 words: hit point, normal, uv, material, ray, light direction, throughput, seed) through LDS, sorted by BSDF type with ballot / popcount ranks, each
 // lane runs the step of the item in ITS slot -- a wave then holds one type, two at a boundary -- and the 16 result words travel back the same way.  Same
 // arithmetic per path, whichever lane does it: bit-identical.  Needs every thread of the block inside the pass (block barriers): launch_logic takes it only
-// when the path count is a multiple of the block size and `first` is off.  It is a template parameter, not a run-time flag: the worker item's 20 inputs on
-// top of the owner's state cost 119 VGPRs against 92 (4 instead of 5 waves per SIMD), which a scene that does not gain from it must not pay.  Round 6:
-// shipped where it wins -- same box, 16 M paths, pass alone / step: courtyard-1440p 2.44 -> 2.11 ms / +3.8 %, egyptcat 1.57 -> 1.47 / +3.4 %, conference
-// 1.89 -> 1.91 / -0.5 % (profiles/r05_regroup_ab.txt) -- i.e. for all-types scenes whose surfaces are mostly of ONE type (a wave of the plain pass then
-// runs that type's step at 2/3 of its lanes and every minority type's step at a handful), not for a scene of three types of similar weight; api.hip picks
-// per scene at upload (option "regroup").
+// when the path count is a multiple of the block size and `first` is off.  It is a template parameter, not a run-time flag, and compiled for 5 blocks per CU
+// (LOGIC_REGROUP_MIN_BLOCKS): round 5's run-time-flag version carried the worker item's 20 inputs on top of the owner's state in EVERY all-types pass -- 119 VGPRs
+// against 92, 4 instead of 5 waves per SIMD -- and won only where one BSDF type dominates (courtyard +3.8 %, egyptcat +3.4 %, conference -0.5 %).  As its own
+// instance under the 5-wave bound the allocator fits it into 96 VGPRs with no scratch (34 SGPRs spilled to lanes), 20.7 KB of LDS per block, and the picture turns
+// round: conference 5392 -> 5678 / 5376 -> 5654 Mrays/s (+5.2 %: three types of similar weight, the case the reference's per-material queues exist for), courtyard
+// and egyptcat within +-0.5 % (profiles/r06_regroup_ab.txt; the 100-VGPR build without the bound, 4 waves: -2 ... -4 % everywhere).  Shipped on for every
+// all-types pass (api.hip: flx_upload_scene, option "regroup").
 #ifndef LOGIC_REGROUP
 #define LOGIC_REGROUP 1
 #endif
@@ -87,7 +88,7 @@ struct LogicAux {
     // in-kernel regeneration (k_logic<FUSE, RAW>, LOGIC_REGEN): one status word per wave for the decoupled look-back over the terminating paths
     unsigned long long *lookback;
     uint32_t epoch;           // launch number: a status word counts only if it carries this launch's epoch (no reset between launches)
-    uint32_t regen;           // 1: terminating lanes are regenerated here (the genRays of this chain is not launched) | 0: off
+    uint32_t regen;           // 1: terminating lanes are regenerated here (the genRays of this chain is not launched) | 2: PREPARED for the genRays that follows (below) | 0: off
     uint32_t appendExt;       // regen: append the regenerated paths to the extension queue at extBase + rank (genRays' appendExt)
     uint32_t *error;          // set when a look-back gives up (never observed; a hang would take the box down, a flag fails the test)
 };
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : 
         // consume the light sample generated at the previous vertex (:135-156)
         // (fetching these four records with the first batch of loads, unconditionally, instead of behind shadowRayBlocked: 110 VGPRs with the
         //  commit's shading record in flight, no gain -- profiles/r03_logic_nee_early_ab.txt)
-        if (st.blocked[gid] == 0u) {
+        const uint32_t blockedOld = st.blocked[gid];
+        if (blockedOld == 0u) {
             float4 le = rd4(st.at(S_LEMIT, gid));
             float4 lb = rd4(st.at(S_LBSDF, gid));
             const float4 lt = rd4(st.at(S_LT, gid));
@@ -275,7 +277,14 @@ __global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : 
         // path (partial sectors again: 0.15-0.19 ms per iteration for 1.8 M paths).  The one thing genRays has that a lane here has not is its index
         // in the raygen queue (= pixel, src/wf_raygen.cl:25): the number of terminating paths with a smaller id -- a decoupled look-back over the waves.
         uint32_t regenRank = 0u, regenLocal = 0u;
-        const bool regen = FULL && aux.regen != 0u;
+        // ---- PREPARED REGENERATION (aux.regen == 2; round 6): what a regenerated path needs is all a function of its seed -- jitter, thin-lens origin, the
+        // reset values -- EXCEPT the pixel (its index in the raygen queue), i.e. except the direction and the pixel word.  k_raygen is bound by its isolated
+        // 16-byte stores into scattered paths (seven per path: four records + three scalars), while this pass stores every record of every lane
+        // anyway: the terminating lane computes jitter + lens origin here, its origin / throughput + new seed / shadowRayBlocked / lastLightPickProb go out with
+        // the full-line stores below, the jitter and the seed after it travel in the (dead) direction record, and the k_raygen of the chain only reads that
+        // record and stores the direction and the pixel (misc.hip: k_raygen, prepared): two scattered stores per path instead of seven.  No look-back needed.
+        const bool regen = FULL && aux.regen == 1u;
+        const bool prep = FULL && aux.regen == 2u;
         if (regen) {
             const uint64_t tb = __ballot(terminate);
             regenRank = lookback_exclusive(aux, gid >> 6, (uint32_t)__popcll(tb)) + mbcnt(tb);
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : 
                         st.pickProb[gid] = neePick;
                     }
                 }
-                if (neeBlocked) st.blocked[gid] = 1u;                 // (a few lanes with an area light behind the surface: left as a partial store)
+                if (!FULL && neeBlocked) st.blocked[gid] = 1u;        // (a few lanes with an area light behind the surface; FULL: with store phase B)
             }
             if (!FULL) wr4(st.at(S_EI, gid), mk4(Ei, eiw));
             (void)Tdirty;
@@ -546,10 +555,21 @@ __global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : 
                 or4 = mk4(ro, 1.0f);                                  // lastPdfW = 1
                 dr4 = mk4u(rd, FLX_FRESH | 0u);                       // pathLen = 0 + "no material kernel since regeneration"
                 thr4 = mk4u(mk3(1.0f), sd);
-                st.blocked[gid] = 1u;                                 // (lastLightPickProb = 1 went out with store phase A)
                 st.firstDiffuse[gid] = 0u;
                 if (aux.appendExt) qs.q[FLX_Q_EXTENSION][ext_len(qs) + regenRank] = gid;
             }
+            if (prep && terminate) {                                  // the seed-only half of genRays (flx_shading.h: camera_ray in parts)
+                uint32_t sd = seed;
+                const float jx = rand01(&sd), jy = rand01(&sd);
+                const uint32_t sd2 = sd;
+                const f3 ro = camera_lens_origin(p, &sd);
+                or4 = mk4(ro, 1.0f);                                  // lastPdfW = 1
+                dr4 = make_float4(jx, jy, __uint_as_float(sd2), __uint_as_float(FLX_FRESH | 0u));      // for k_raygen: jitter + the seed behind it (it redoes the lens draws)
+                thr4 = mk4u(mk3(1.0f), sd);                           // T = 1, the seed genRays leaves
+            }
+            // shadowRayBlocked: every lane, one store (was a partial one of the few lanes with the area light behind the surface): 1 for those, genRays' 1 for a
+            // lane regenerated or prepared here (lastLightPickProb = 1 went out with store phase A), else what the lane loaded
+            st.blocked[gid] = (neeBlocked || ((regen || prep) && terminate)) ? 1u : blockedOld;
             wr4(st.at(S_LBSDF, gid), lbs);
             wr4(st.at(S_LT, gid), lt4);
             wr4(st.at(S_THR, gid), thr4);
@@ -685,25 +705,6 @@ __global__ __launch_bounds__(LOGIC_BLOCK) void k_queue_scatter(Queues qs, LogicA
         r += mbcnt(bal[0] | bal[2] | bal[3] | bal[4] | bal[5] | bal[6]);
         qs.q[FLX_Q_EXTENSION][ext_len(qs) + r] = gid;
     }
-    if (fuse != 0 && byPathId == 3u && ((member & 1u) != 0u || ml != 0u)) {
-        // ext order 3 (api.hip: EARLY EXTENSION START): the same set as order 2 in TWO segments, each in path-id order --
-        //   A  the continuing paths whose material step this pass has inlined: their new rays are complete when this pass is, so the persistent closest-hit
-        //      kernel starts on them at once, beside genRays and the material kernel of the other BSDF types;
-        //   B  the regenerated paths and the continuing paths of the types that are not inlined: traced behind those two kernels.
-        // |A| = the final counters of the inlined lists (the scan ran before this kernel).
-        const bool inA = ml != 0u && fuse_inlines_list(fuse, ml);
-        uint32_t r = 0u, nA = 0u;
-        uint64_t mA = 0ull, mB = bal[0];
-        #pragma unroll
-        for (int l = 2; l < NUM_LISTS; l++) {
-            const bool a = fuse_inlines_list(fuse, (uint32_t)(l - 1));
-            if (a) { mA |= bal[l]; nA += qs.counters[FLX_Q_DIFFUSE + (l - 2)]; } else mB |= bal[l];
-            if (a == inA) { r += s_off[l]; for (uint32_t w = 0; w < wave; w++) r += s_cnt[l][w]; }
-        }
-        if (!inA) { r += s_off[0]; for (uint32_t w = 0; w < wave; w++) r += s_cnt[0][w]; }
-        r += mbcnt(inA ? mA : mB);
-        qs.q[FLX_Q_EXTENSION][ext_len(qs) + (inA ? 0u : nA) + r] = gid;
-    }
 }
 
 // elements per list in the block-count / block-offset arrays (api.hip allocates NUM_LISTS x this, zero-filled)
@@ -729,7 +730,7 @@ void launch_logic(hipStream_t s, const State &st, const Queues &qs, const Scene 
 {
     // the reference launches ceil32(NUM_TASKS) work-items (src/clcontext.cpp:792); here ceil256
     uint32_t blocks = (st.numTasks + LOGIC_BLOCK - 1) / LOGIC_BLOCK;
-    LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks), lookback, epoch, (uint32_t)(raw && regen), (uint32_t)regenAppendExt, error};
+    LogicAux aux{member, blockCounts, blockOffsets, blocks, logic_aux_stride(st.numTasks), lookback, epoch, (uint32_t)(raw ? regen : 0), (uint32_t)regenAppendExt, error};
     // the BSDF-uniform material step needs every thread of every block inside the pass (block barriers): whole blocks of paths, no `first` cut-off
     const bool rg = LOGIC_REGROUP && raw && regroup && fuse == USE_ALL && !firstIteration && st.numTasks % LOGIC_BLOCK == 0u;
     const dim3 g(blocks), b(LOGIC_BLOCK);

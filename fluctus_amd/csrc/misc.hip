@@ -50,16 +50,30 @@ __global__ __launch_bounds__(MISC_BLOCK) void k_reset(State st, Queues qs, Frame
 
 // appendExt 0: the extension-queue entries of the regenerated paths were written already -- by the fused scatter, merged with the continuing
 // paths into ONE list in path-id order (logic.hip: k_queue_scatter, ext_order 2) -- and only the paths are regenerated here
-__global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p, uint32_t appendExt)
+// prepared 1 (PREPARED REGENERATION, logic.hip): the fused RAW pass of this chain has stored everything of the regenerated paths that does not depend on the
+// pixel -- origin, throughput + the seed genRays leaves, shadowRayBlocked, lastLightPickProb -- and left {jitter x, jitter y, seed after the jitter} in the
+// direction record: only the direction and the pixel word are stored here (two scattered 16-byte stores per path instead of four + three scalars; this kernel
+// is bound by them).  The lens origin is recomputed from the seed (same function, same bits) rather than gathered.
+__global__ __launch_bounds__(MISC_BLOCK) void k_raygen(State st, Queues qs, Frame fr, flx_render_params p, uint32_t appendExt, uint32_t prepared)
 {
     const uint32_t qlen = qs.counters[FLX_Q_RAYGEN];
     // capped grid striding over the queue (its length is only known here; see MAT_GRID in material.hip)
     for (uint32_t gd = blockIdx.x * MISC_BLOCK + threadIdx.x; gd < qlen; gd += gridDim.x * MISC_BLOCK) {
         const uint32_t gid = qs.q[FLX_Q_RAYGEN][gd];
-        uint32_t seed = __float_as_uint(rd4t(st.at(S_THR, gid)).w);
         // pixel cursor over the rank's local pixels; local p <-> global p*nranks + rank
         // (1 rank: the reference's (cur + gid_direct) % numPixels, src/wf_raygen.cl:25)
         const uint32_t localIdx = (*fr.currPixelIdx + gd) % fr.localPixels;
+        if (prepared) {
+            const float4 j4 = rd4t(st.at(S_DIR, gid));
+            uint32_t sd = __float_as_uint(j4.z);
+            const f3 lens = camera_lens_origin(p, &sd);
+            wr4(st.at(S_DIR, gid), mk4u(camera_direction(fr, p, localIdx, j4.x, j4.y, lens), FLX_FRESH | 0u));
+            wr4(st.at(S_EI, gid), mk4u(mk3(0.0f), FLX_FRESH | localIdx));
+            if (st.firstDiffuse[gid]) st.firstDiffuse[gid] = 0u;     // (a read instead of a third scattered store: the flag is set only while the denoiser features accumulate)
+            if (appendExt) qs.q[FLX_Q_EXTENSION][ext_len(qs) + gd] = gid;
+            continue;
+        }
+        uint32_t seed = __float_as_uint(rd4t(st.at(S_THR, gid)).w);
         f3 rayOrig, rayDirection;
         camera_ray(fr, p, localIdx, &seed, &rayOrig, &rayDirection);
 
@@ -217,11 +231,11 @@ void launch_reset(hipStream_t s, const State &st, const Queues &qs, const Frame 
     uint32_t n = st.numTasks > fr.localPixels ? st.numTasks : fr.localPixels;      // src/clcontext.cpp:767
     hipLaunchKernelGGL(k_reset, dim3((n + MISC_BLOCK - 1) / MISC_BLOCK), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, n);
 }
-void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p, int appendExt)
+void launch_raygen(hipStream_t s, const State &st, const Queues &qs, const Frame &fr, const flx_render_params &p, int appendExt, int prepared)
 {
     uint32_t blocks = (st.numTasks + MISC_BLOCK - 1) / MISC_BLOCK;
     if (blocks > 2048u) blocks = 2048u;
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, (uint32_t)appendExt);
+    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(MISC_BLOCK), 0, s, st, qs, fr, p, (uint32_t)appendExt, (uint32_t)prepared);
 }
 // the per-texel table of next-event estimation (flx_device.h: Scene::neeRec)
 __global__ __launch_bounds__(MISC_BLOCK) void k_env_nee_table(Scene sc, float4 *out, uint32_t n)

@@ -46,24 +46,15 @@ unsigned long long *g_lab_rstats = nullptr;
 #endif
 
 template <bool ANY_HIT, int ANY_ORDER>
-__global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax, uint32_t *cursor, uint32_t segBegin, uint32_t segLen)
+__global__ __launch_bounds__(WIDE_BLOCK, WIDE_R_MIN_WAVES) void k_trace4r(State st, Queues qs, Scene sc, flx_render_params p, TraceAux aux, int refillMin, int waitMax, uint32_t *cursor)
 {
     __shared__ uint32_t s_stack[WIDE_LDS_LEVELS * WIDE_BLOCK];
 #ifdef FLX_LAB_RSTATS
     unsigned long long *rstats = aux.stats; unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     const int QID = ANY_HIT ? FLX_Q_SHADOW : FLX_Q_EXTENSION;
-    // segLen != 0 (closest hit only): ONE SEGMENT of the extension queue -- entries [counters[EXTENSION] + sum of counters[q], q in segBegin) of length
-    // sum of counters[q], q in segLen -- instead of the whole queue (api.hip: EARLY EXTENSION START; the fused scatter lays the queue out in two such segments)
-    uint32_t qbeg = 0u, qlen_ = ANY_HIT ? qs.counters[QID] : 0u;
-    if (!ANY_HIT) {
-        if (segLen) {
-            qbeg = qs.counters[FLX_Q_EXTENSION];
-            for (int q = 0; q < FLX_NUM_QUEUES; q++) { if (segBegin & (1u << q)) qbeg += qs.counters[q]; if (segLen & (1u << q)) qlen_ += qs.counters[q]; }
-        } else qlen_ = ext_len(qs);
-    }
-    const uint32_t qlen = qlen_;
-    const uint32_t *queue = qs.q[QID] + qbeg;
+    const uint32_t qlen = ANY_HIT ? qs.counters[QID] : ext_len(qs);
+    const uint32_t *queue = qs.q[QID];
     const uint32_t nblk = (qlen + 63u) >> 6;
     // Which 64-ray block next.  Rays differ in cost by an order of magnitude (sky vs. foliage), so a static share per wave (blocks w, w + G, ...)
     // leaves wave slots idle towards the end of the launch (courtyard: 1.60 -> 1.50 ms with this; kitchen and conference unchanged).  Blocks
@@ -242,15 +233,17 @@ static uint32_t persistent_grid(K kernel, int &cached, uint32_t numCUs, uint32_t
 #else
     (void)capEnv;
 #endif
-    const uint32_t g = numCUs * (uint32_t)perCU;
+    uint32_t g = numCUs * (uint32_t)perCU;
     const uint32_t blocks = (numTasks + 63u) / 64u;
+    // A wave should get at least ~3 blocks of 64 rays: with fewer the launch is all ramp-up and tail (the refill has nothing to refill from).  Matters only for small
+    // wavefronts -- the reference's own wfBufferSize of 2^20 paths is 16 384 blocks for 7 168 wave slots: capped at 14 ... 20 waves per CU the kitchen step gains 3.5 %
+    // there (3750-3765 -> 3884-3896 Mrays/s), at 4 M paths and beyond the cap is not reached (profiles/r06_small_wavefront_grid.txt; fewer than 20 per CU lose at 4 M).
+    if (blocks / 3u < g) g = blocks / 3u > numCUs ? blocks / 3u : numCUs;
     return g < blocks ? g : blocks;
 }
 
 // refill = refillMin | waitMax << 8.  Leaves RAW hit records behind (the caller remembers: api.hip, flx_ctx::rawHits).
-// segBegin / segLen: queue-counter masks of one segment of the extension queue (k_trace4r), 0 / 0 = the whole queue; wavesPerCU > 0 caps the persistent grid
-void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor,
-                     uint32_t segBegin, uint32_t segLen, int wavesPerCU)
+void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Scene &sc, const flx_render_params &p, uint32_t *spill, uint32_t numCUs, int refill, uint32_t *cursor)
 {
     const int refillMin = (refill & 0xFF) ? (refill & 0xFF) : 1, waitMax = ((refill >> 8) & 0xFF) ? ((refill >> 8) & 0xFF) : 64;      // (refillMin 0 would spin: api.hip, refill_value_ok)
     static int occ = 0;
@@ -258,9 +251,8 @@ void launch_extend4r(hipStream_t s, const State &st, const Queues &qs, const Sce
 #ifdef FLX_LAB_RSTATS
     aux.stats = g_lab_rstats;
 #endif
-    uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_EXT");
-    if (wavesPerCU > 0 && numCUs * (uint32_t)wavesPerCU < grid) grid = numCUs * (uint32_t)wavesPerCU;
-    hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor, segBegin, segLen);
+    const uint32_t grid = persistent_grid(k_trace4r<false, 0>, occ, numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_EXT");
+    hipLaunchKernelGGL((k_trace4r<false, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
 }
 
 void launch_materialise(hipStream_t s, const State &st, const Scene &sc, const flx_render_params &p, uint32_t numCUs)
@@ -276,10 +268,10 @@ void launch_shadow4r(hipStream_t s, const State &st, const Queues &qs, const Sce
     // visit order of the any-hit traversal (trace4.hip: launch_shadow4): far -> near when every shadow ray runs toward the environment light
     if (p.useEnvMap && !p.useAreaLight) {
         const uint32_t grid = persistent_grid(k_trace4r<true, 1>, occ[1], numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_SHADOW");
-        hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor, 0u, 0u);
+        hipLaunchKernelGGL((k_trace4r<true, 1>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     } else {
         const uint32_t grid = persistent_grid(k_trace4r<true, 0>, occ[0], numCUs, st.numTasks, "FLX_PERSISTENT_WAVES_SHADOW");
-        hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor, 0u, 0u);
+        hipLaunchKernelGGL((k_trace4r<true, 0>), dim3(grid), dim3(WIDE_BLOCK), 0, s, st, qs, sc, p, aux, refillMin, waitMax, cursor);
     }
     if (p.useAreaLight) hipLaunchKernelGGL(k_lightfix4, dim3(numCUs * 8), dim3(256), 0, s, st, qs, p);
 }

@@ -23,7 +23,7 @@ SYMBOLS = ["flx_create", "flx_destroy", "flx_last_error", "flx_upload_scene", "f
            "flx_queue_read", "flx_queue_write", "flx_set_counters", "flx_set_option", "flx_get_option", "flx_mk_reset", "flx_mk_raygen", "flx_mk_next_vertex",
            "flx_mk_sample_bsdf", "flx_mk_splat", "flx_mk_splat_preview", "flx_mk_stats_async", "flx_mk_stats_reset"]
 
-KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7, "logic_fused": 8, "extend_b": 9}
+KERNELS = {"reset": 0, "raygen": 1, "extend": 2, "shadow": 3, "logic": 4, "materials": 5, "postprocess": 6, "trace_span": 7, "logic_fused": 8}
 
 
 def _preload_torch_runtime():

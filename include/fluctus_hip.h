@@ -152,9 +152,7 @@ enum { FLX_K_RESET = 0, FLX_K_RAYGEN = 1, FLX_K_EXTEND = 2, FLX_K_SHADOW = 3, FL
        FLX_K_POSTPROCESS = 6,
        FLX_K_TRACE_SPAN = 7,   /* start of the extension kernel .. end of the (concurrent) shadow kernel */
        FLX_K_LOGIC_FUSED = 8,  /* logic + the inlined material step as one pass (option "fuse"); FLX_K_MATERIALS then covers the rest */
-       FLX_K_EXTEND_B = 9,     /* option "early_ext": the extension kernel's second launch (regenerated paths + paths of the BSDF types the fused pass does not inline);
-                                  FLX_K_EXTEND is then the first launch, on the paths whose material step the fused pass inlined */
-       FLX_K_COUNT = 10 };
+       FLX_K_COUNT = 9 };
 /* on: 0 off | 1 time every kernel | 2 time only the two trace kernels (+ their span), as the reference does | 3 only the
  * extension kernel | 4 the three kernels bench.py prices against a roof: extension, logic (the fused pass incl. its queue scan + scatter), shadow.
  * Each event pair costs a few microseconds of stream time, which shows at ~11 launches per 0.7 ms
@@ -221,7 +219,15 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     material queues empty (flx_clear_queues / flx_end_iteration_async since the last logic) and wfSeparateQueues
  *                     (or a build that inlines every type) -- otherwise, and with 0, every call launches its own kernels at once
  *   fuse_set          BSDF types the fused pass inlines: 1 diffuse only | 31 all six.  flx_upload_scene picks it from the scene
- *                     (diffuse surfaces >= 3/4 of the triangle area: 1, else 31); set it after the upload to override
+ *                     (diffuse surfaces >= 3/4 of the triangle area: 1, else 31); set it after the upload to override.  OVERRIDDEN while
+ *                     params.wfSeparateQueues == 0: with a single material queue every BSDF type sits in the diffuse list and only the pass
+ *                     that inlines all types can serve it, so that pass runs whatever fuse_set says -- flx_get_option("fuse_set") still returns
+ *                     the stored value, the read-only "fuse_set_now" the set the next fused pass will really inline (an A/B of fuse_set under a
+ *                     single material queue compares the all-types pass with itself)
+ *   regroup           the all-types fused pass hands its material step through LDS sorted by BSDF type, so that a wave runs one type
+ *                     (logic.hip: LOGIC_REGROUP; 96 VGPRs + 20 KB of LDS per block): 0 | 1 | -1 (default) = on; flx_get_option returns the
+ *                     effective value.
+ *                     Bit-identical results.  Takes effect when the path count is a multiple of 256 (whole blocks)
  *   ext_order         how the fused pass lists the traced paths in the extension queue: 0 one segment per material queue, in the
  *                     separate kernels' order | 1 all continuing paths by path id | 2 continuing AND regenerated paths merged into one
  *                     list by path id (genRays then does not append; needs genRays between logic and the material kernels, else as 1).

@@ -391,12 +391,10 @@ class RefGpuContext:
             B.write(self.scene[k], arr)
 
     def upload_envmap(self, e):
-        """gfx950 has no image support (CL_DEVICE_IMAGE_SUPPORT = 0), so no runtime can create the image2d_t `logic` expects.  Through the HIP module
-        loader the kernel's 8-byte image slot takes a plain pointer, and the logic_v<id>_imgstandin.co builds (oracle/ref/Makefile GERULE: the reference's
+        """gfx950 has no image support (CL_DEVICE_IMAGE_SUPPORT = 0), so no runtime can create the image2d_t `logic` expects.  In the
+        logic_v<id>_imgstandin.co builds the kernel's 8-byte image slot is tagged a plain global pointer (oracle/ref/Makefile GERULE, last step), and they (the reference's
         wf_logic.cl unmodified, AMD's built-in library for everything EXCEPT read_imagef / get_image_dim, which come from the builder-written
         oracle/ref/gfx950_image_standin.cl) read {int w, h, 0, 0; float4 texels[w * h]} behind it.  A stand-in for the image filter only; labelled so."""
-        if self.B.name != "hip":
-            raise ImageArgUnsupported("gfx950 has no image support: the env map needs the hip loader and the image stand-in build (backend_name='hip')")
         if not available_env(self.flavour):
             raise RefGpuUnavailable(f"{co_dir(self.flavour)}/logic_v*_imgstandin.co not built (make -C oracle/ref gfx950)")
         B = self.B

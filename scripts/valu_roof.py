@@ -182,7 +182,8 @@ def main():
         shutil.rmtree(tmp, ignore_errors=True)
     want = {"k_trace4r<false, 0>": "trace", "k_trace4r<true, 1>": "shadow", "k_trace4r<true, 0>": "shadow",
             "k_shadow4<false, 1>": "shadow", "k_shadow4<false, 0>": "shadow", "k_extend4<false>": "trace",
-            "k_logic<1, true>": "logic", "k_logic<31, true>": "logic", "k_logic<0, false>": "logic", "k_logic<1, false>": "logic", "k_logic<31, false>": "logic",
+            "k_logic<1, true, false>": "logic", "k_logic<31, true, false>": "logic", "k_logic<31, true, true>": "logic", "k_logic<0, false, false>": "logic",
+            "k_logic<1, false, false>": "logic", "k_logic<31, false, false>": "logic",
             "k_raygen": "logic", "k_material_rest": "logic", "k_material<31>": "logic", "k_queue_scatter": "logic"}
     out = {"source_hash": build.source_hash(), "library": os.path.basename(args.lib), "model": {"pipe_time": COST, "rule": "cycles = max(S + T + P work, (all work) / 2); F and M issue on either pipe"},
            "ubench": ["profiles/r03_ubench_valu_rate.txt", "profiles/r03_ubench_valu_pairs.txt", "profiles/r03_ubench_valu_pairs_membership.txt"], "kernels": {}}

@@ -44,7 +44,7 @@ def _gen_sequence(rng):
             op = chain[pos % len(chain)]; pos += 1
         else:
             op = rng.choice(["logic", "raygen", "materials", "extend", "shadow", "clear", "counters", "finish", "params", "export", "qread",
-                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals", "opt_regen", "opt_regroup", "opt_early"])
+                             "opt_fuse", "opt_refill", "opt_tree", "opt_fuseset", "opt_overlap", "pixidx", "end_iter", "pixels", "opt_shadow", "totals", "opt_regen", "opt_regroup", "opt_prep"])
         if op == "logic":
             if logic_done:
                 continue
@@ -77,8 +77,8 @@ def _gen_sequence(rng):
             seq.append(("opt", "regen", int(rng.randint(0, 2))))
         elif op == "opt_regroup":                     # all-types RAW pass with its material step sorted by BSDF type through LDS (logic.hip: LOGIC_REGROUP) on / off
             seq.append(("opt", "regroup", int(rng.randint(0, 2))))
-        elif op == "opt_early":                       # extension queue in two segments, the first traced behind `logic` alone on a third stream (api.hip: EARLY EXTENSION START)
-            seq.append(("opt", "early_ext", int(rng.choice([0, 6, 28]))))
+        elif op == "opt_prep":                        # prepared regeneration: the seed-only half of genRays inside the fused RAW pass (logic.hip) on / off
+            seq.append(("opt", "regen_prep", int(rng.randint(0, 2))))
         elif op == "opt_overlap":
             seq.append(("opt", "overlap", int(rng.choice([0, 1, 2]))))
         elif op == "pixidx":
@@ -148,12 +148,12 @@ def test_call_sequence_fuzz(separate_queues, seed, n):
         hi = sg.view(np.uint32)[COL.HIT_I]
         exported_raw += int((((hi >> 30) & 3) == 1).sum())
 
-    def run(seq, fuse_set, ext_order, regen, regroup, early, what, check_each=False):
+    def run(seq, fuse_set, ext_order, regen, regroup, prep, what, check_each=False):
         nonlocal cursor
         g.set_option("fuse", 1); g.set_option("extend_tree", 4); g.set_option("refill_extend", 16 | (32 << 8)); g.set_option("overlap", 2)
         g.set_option("shadow_tree", 4); g.set_option("refill_shadow", 0)
         g.set_option("fuse_set", fuse_set); g.set_option("ext_order", ext_order); g.set_option("regen", regen)
-        g.set_option("regroup", regroup); g.set_option("early_ext", early)
+        g.set_option("regroup", regroup); g.set_option("regen_prep", prep)
         for c in (g, o):
             c.set_params(p)
         for k, op in enumerate(seq):
@@ -214,16 +214,16 @@ def test_call_sequence_fuzz(separate_queues, seed, n):
         # (the shipped default of the diffuse-only pass: the scatter writes the regenerated paths' entries and the deferred genRays must not append)
         ext_order = int(rng.choice([0, 1, 2]))
         regen = int(rng.randint(0, 2))                 # the fused RAW pass regenerates its terminating paths itself (logic.hip: REGEN) | genRays does
+        prep = int(rng.randint(0, 2))                  # prepared regeneration (the shipped default is 1)
         regroup = int(rng.randint(0, 2))               # the all-types RAW pass sorts its material step by BSDF type per block (takes effect with whole blocks of paths)
-        early = int(rng.choice([0, 6, 28]))            # early start of the closest-hit kernel on the inlined paths' segment of the queue (0 off | waves per CU)
         # every sequence starts from the oracle's current state, queues cleared
         for c in (g, o):
             c.clear_queues()
         common.sync(g, o)
         start, cursor0 = o.state_export(), cursor
-        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}, regen {regen}, regroup {regroup}, early_ext {early}) {seq}"
+        what = f"sequence {s} (fuse_set {fuse_set}, ext_order {ext_order}, regen {regen}, regroup {regroup}, regen_prep {prep}) {seq}"
         try:
-            run(seq, fuse_set, ext_order, regen, regroup, early, what)
+            run(seq, fuse_set, ext_order, regen, regroup, prep, what)
         except AssertionError:
             # locate the call: same sequence from the same state, everything compared after every call
             for c in (g, o):
@@ -231,7 +231,7 @@ def test_call_sequence_fuzz(separate_queues, seed, n):
             cursor = cursor0
             for c in (g, o):
                 set_cursor(c)
-            run(seq, fuse_set, ext_order, regen, regroup, early, what, check_each=True)
+            run(seq, fuse_set, ext_order, regen, regroup, prep, what, check_each=True)
             raise
     assert exported_raw == 0, f"{exported_raw} RAW hit records were exported"
     phases = sorted({c[0] for c in covered})

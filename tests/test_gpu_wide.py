@@ -557,50 +557,6 @@ def test_refill_kernels_are_bit_identical_to_thread_per_ray(workload, refill):
         g.close()
 
 
-@pytest.mark.parametrize("workload,cap", [("kitchen", 28), ("kitchen", 12), ("conference", 28), ("egyptcat", 20), ("courtyard-1440p", 28)])
-def test_early_extension_start_is_bit_identical(workload, cap):
-    """Option `early_ext` (api.hip: EARLY EXTENSION START): the extension queue in two segments -- the paths whose material step the fused pass inlined, traced by
-    a launch of the persistent closest-hit kernel that starts behind `logic` alone, beside genRays and the material kernel; the regenerated paths and the paths of
-    the other BSDF types, traced by a second launch behind those two -- against the single launch over the whole queue.  Which launch traces a ray changes nothing
-    about the ray: two contexts free-run the workload at 1 M paths (diffuse-inline pass = ext order 3 on the kitchen; all-types pass = order 1's own
-    [regenerated | continuing] split on the conference scene and the courtyard; single material queue on egyptcat), counters after every iteration, the extension
-    queue as a set, the whole state after 3 and 12 iterations, the framebuffers.  cap = persistent waves per CU of the early launch."""
-    from fluctus_amd.device import HipContext
-    import bench
-    d, p, env = bench.build_workload(name=workload)
-    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
-    ctx = []
-    for e in (0, cap):
-        g = HipContext(n)
-        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); g.set_option("early_ext", e); driver.reset_renderer(g)
-        ctx.append(g)
-    a, b = ctx
-    assert a.get_option("early_ext") == 0 and b.get_option("early_ext") == cap and a.get_option("ext_order") == b.get_option("ext_order")
-    for it in range(12):
-        for g in (a, b):
-            g.wf_logic(False); g.wf_raygen(); g.wf_materials()
-        ca, cb = a.get_counters(), b.get_counters()
-        if it in (1, 7):                                   # the queue itself: the same set of paths (this read-back breaks the chain: this iteration runs as one launch)
-            a.finish()
-            ne = int(np.array(ca, copy=True)[Q.EXTENSION])
-            assert np.array_equal(np.sort(a.queue_read(Q.EXTENSION)[:ne]), np.sort(b.queue_read(Q.EXTENSION)[:ne])), f"{workload} it{it}: extension queues hold different paths"
-        for g in (a, b):
-            g.wf_extend(); g.wf_shadow(); g.clear_queues(); g.finish()
-        ca, cb = np.array(ca, copy=True), np.array(cb, copy=True)
-        assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
-        for g in (a, b):
-            g.pixel_index_update(npix, int(ca[Q.RAYGEN]))
-        if it == 2:
-            fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
-            assert not fails, "after 3 iterations: " + "; ".join(fails[:5])
-    fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
-    assert not fails, "; ".join(fails[:5])
-    pa, pb = a.read_pixels(0), b.read_pixels(0)
-    assert np.array_equal(pa[:, 3], pb[:, 3]) and common.fb_close(pa, pb)
-    for g in ctx:
-        g.close()
-
-
 @pytest.mark.parametrize("workload", ["kitchen", "conference"])
 def test_in_kernel_regeneration_is_bit_identical_to_genrays(workload):
     """Option `regen` (logic.hip: REGEN): the fused RAW pass regenerates its terminating paths itself -- their index in the raygen queue (= pixel,
@@ -627,6 +583,40 @@ def test_in_kernel_regeneration_is_bit_identical_to_genrays(workload):
             assert not fails, "after 3 iterations: " + "; ".join(fails[:5])
     fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
     assert not fails, "; ".join(fails[:5])
+    pa, pb = a.read_pixels(0), b.read_pixels(0)
+    assert np.array_equal(pa[:, 3], pb[:, 3]) and common.fb_close(pa, pb)
+    for g in ctx:
+        g.close()
+
+
+@pytest.mark.parametrize("workload", ["kitchen", "conference", "egyptcat"])
+def test_prepared_regeneration_is_bit_identical_to_genrays(workload):
+    """Option `regen_prep` (default on; logic.hip: PREPARED REGENERATION): the fused RAW pass computes the seed-only half of genRays for its terminating lanes
+    (jitter, thin-lens origin, throughput + new seed, the reset scalars: stored with its full-line stores) and the k_raygen of the chain only the direction and
+    the pixel -- against the whole of genRays in k_raygen.  Two contexts free-run the workload at 1 M paths: counters after every iteration, the whole state after
+    3 and 12 iterations (the first export happens right behind a chain that used the split), the framebuffers."""
+    from fluctus_amd.device import HipContext
+    import bench
+    d, p, env = bench.build_workload(name=workload)
+    n, npix = 1 << 20, int(p["width"]) * int(p["height"])
+    ctx = []
+    for r in (0, 1):
+        g = HipContext(n)
+        g.upload_scene(d); g.upload_envmap(env); g.set_params(p); g.set_option("regen_prep", r); driver.reset_renderer(g)
+        ctx.append(g)
+    a, b = ctx
+    assert a.get_option("regen_prep") == 0 and b.get_option("regen_prep") == 1
+    for it in range(12):
+        ca, cb = driver.benchmark_iteration(a, npix), driver.benchmark_iteration(b, npix)
+        assert (ca == cb).all(), f"{workload} it{it}: {ca} vs {cb}"
+        if it in (2, 5):
+            fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+            assert not fails, f"after {it + 1} iterations: " + "; ".join(fails[:5])
+    # ... and with the state looked at right behind the chain (logic -> genRays -> materials), before the extension kernel: the regenerated paths as genRays leaves them
+    for g in (a, b):
+        g.wf_logic(False); g.wf_raygen(); g.wf_materials()
+    fails = common.state_diff(a.state_export(), b.state_export(), 0.0, 0.0)
+    assert not fails, "behind the chain: " + "; ".join(fails[:5])
     pa, pb = a.read_pixels(0), b.read_pixels(0)
     assert np.array_equal(pa[:, 3], pb[:, 3]) and common.fb_close(pa, pb)
     for g in ctx:
