@@ -75,6 +75,9 @@ __host__ __device__ constexpr bool fuse_inlines_list(int fuse, uint32_t ml)     
 #ifndef LOGIC_REGROUP
 #define LOGIC_REGROUP 1
 #endif
+#ifndef LOGIC_LAZY_HITN
+#define LOGIC_LAZY_HITN 1
+#endif
 #ifndef LOGIC_REGROUP_MIN_BLOCKS      // blocks per CU the regrouped pass is compiled for (x 4 waves per block / 4 SIMDs = waves per SIMD)
 #define LOGIC_REGROUP_MIN_BLOCKS 5
 #endif
@@ -177,8 +180,13 @@ __global__ __launch_bounds__(LOGIC_BLOCK, (REGROUP ? LOGIC_REGROUP_MIN_BLOCKS : 
         const float4 thr = rd4(st.at(S_THR, gid));
         const float4 d4 = rd4(st.at(S_DIR, gid));
         const float4 o4 = rd4(st.at(S_ORIG, gid));
-        const float4 hn = rd4(st.at(S_HITN, gid));
         const float4 huv = rd4(st.at(S_HITUV, gid));
+        // The old normal record is needed only by a path WITHOUT a RAW hit record (committed by k_materialise, or never traced since its regeneration): a RAW path's
+        // normal and flags come from the commit below, and the one bit it would keep from the old record (backfaceHit, hit_keep_flags) is rewritten by every store of
+        // this pass.  In the RAW pass almost every path is raw: 16 B per path less to read (LOGIC_LAZY_HITN; round 4 measured it inside the noise of a pass that was
+        // still paying for partial writes -- profiles/r04_lazy_hitn_ab.txt; round 6: profiles/r06_lazy_hitn_ab.txt).
+        float4 hn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!(RAW && LOGIC_LAZY_HITN != 0 && hit_is_raw(__float_as_uint(huv.z)))) hn = rd4(st.at(S_HITN, gid));
         const float4 ei4 = rd4(st.at(S_EI, gid));
         uint32_t seed = __float_as_uint(thr.w);
         const uint32_t pixIdx = __float_as_uint(ei4.w) & ~FLX_FRESH;

@@ -224,6 +224,11 @@ int flx_set_counters(flx_ctx *ctx, const void *in32);
  *                     that inlines all types can serve it, so that pass runs whatever fuse_set says -- flx_get_option("fuse_set") still returns
  *                     the stored value, the read-only "fuse_set_now" the set the next fused pass will really inline (an A/B of fuse_set under a
  *                     single material queue compares the all-types pass with itself)
+ *   regen_prep        1 (default) | 0: inside the fused chain logic -> genRays -> materials the RAW logic pass computes, for the paths it terminates, the half
+ *                     of genRays that is a function of the path's seed alone (jitter, thin-lens origin, throughput + the seed genRays leaves,
+ *                     shadowRayBlocked, lastLightPickProb) and stores it with its full-line stores; the genRays launch of the same chain then stores
+ *                     only the direction and the pixel (logic.hip / misc.hip: PREPARED REGENERATION).  Bit-identical results; no call can run
+ *                     between the two launches
  *   regroup           the all-types fused pass hands its material step through LDS sorted by BSDF type, so that a wave runs one type
  *                     (logic.hip: LOGIC_REGROUP; 96 VGPRs + 20 KB of LDS per block): 0 | 1 | -1 (default) = on; flx_get_option returns the
  *                     effective value.

@@ -12,7 +12,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_${TAG}_$W
 rm -rf $OUT; mkdir -p $OUT $REPO/profiles
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --workload $W --steps 20 --warmup 16 --windows 1 --no-cpu-baseline $*"
+CMD="python $REPO/bench.py --workload $W --steps 20 --warmup 16 --windows 1 --no-cpu-baseline --no-ref-gpu-baseline $*"      # (the reference's OpenCL kernels are not what is profiled here)
 cd /tmp
 timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
 grep '^{' $OUT/trace.log > $REPO/profiles/${TAG}_${W}_bench.json
@@ -25,3 +25,5 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_
 done
 cd $REPO
 python scripts/summarize_round.py $OUT $TAG $W "$*"
+# gpurun merges at most 64 MiB back: keep the kernel trace (the timeline is made from it), drop the eight counter passes' raw CSVs once they are summarised
+rm -rf $OUT/p[0-9]*

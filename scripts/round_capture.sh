@@ -22,6 +22,7 @@ for W in $WLS; do
   T=$(ls gpurun_out/prof_${TAG}_$W/trace/*/*kernel_trace.csv 2>/dev/null | head -1)
   [ -n "$T" ] && python scripts/timeline.py $T > profiles/${TAG}_${W}_timeline.txt 2>&1
   cp profiles/${TAG}_${W}_* profiles/traffic_$W.json $DST/ 2>/dev/null
+  rm -rf gpurun_out/prof_${TAG}_$W                  # (raw traces: tens of MB per workload; everything judged is in $DST by now)
 done
 python bench.py 2>gpurun_out/${TAG}_final_bench.err | grep '^{' > $DST/${TAG}_final_bench.json
 python - <<PY

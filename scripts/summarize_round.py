@@ -13,7 +13,7 @@ out, tag, wl, extra = sys.argv[1], sys.argv[2], sys.argv[3], (sys.argv[4] if len
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
-    shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
+    shutil.copy(f, os.path.join(prof, f"{tag}_{wl}_kernel_stats_whole_process.csv"))      # rocprofv3's own summary: every dispatch of the process (settling, extra untimed passes)
 KEYS = ("k_trace4r<false", "k_trace4r<true", "k_extend4<false>", "k_shadow4<false", "k_shadow4s<", "k_commit4", "k_lightfix4", "k_extend<false>", "k_shadow<false>", "k_logic", "k_material", "k_raygen",
         "k_queue_scatter", "k_queue_scan")
 bench = {}
@@ -27,6 +27,25 @@ skip = int(bench.get("settle_iterations", 0))
 # ... and (round 5) only the TIMED WINDOW's dispatches: bench.py runs extra untimed passes behind it (serial schedule, counting variants); the kernels of the
 # default chain launch once per iteration, so dispatches [skip, skip + steps x windows) of a kernel are the timed ones
 timed = int(bench.get("steps", 0)) * int((bench.get("windows") or {}).get("count", 1))
+# <tag>_<workload>_kernel_stats.csv (round 6): per-kernel statistics of the TIMED WINDOW only, from the kernel trace -- rocprofv3's own summary averages every
+# dispatch of the process, and the launches beside bench.py's 0.5-s counting variants behind the timed window polluted it (k_material_rest "avg 6 ms, max 84 ms").
+# The window = [start of the fused logic kernel's dispatch number `skip`, start of its dispatch number `skip + timed`): one logic dispatch per iteration.
+for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+    rows.sort()
+    lg = [r for r in rows if "k_logic" in r[2]]
+    if timed and len(lg) > skip + timed:
+        t0, t1 = lg[skip][0], lg[skip + timed][0]
+        st = collections.defaultdict(list)
+        for a, b, k in rows:
+            if t0 <= a < t1:
+                st[k].append(b - a)
+        tot = sum(sum(v) for v in st.values()) or 1
+        with open(os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"), "w") as fo:
+            w = csv.writer(fo)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", f"# timed window only: {timed} iterations behind the first {skip}; window {(t1 - t0) / 1e6:.3f} ms = {(t1 - t0) / 1e6 / timed:.4f} ms per iteration"])
+            for k, v in sorted(st.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([k, len(v), sum(v), "%.1f" % (sum(v) / len(v)), "%.2f" % (100.0 * sum(v) / tot), min(v), max(v), ""])
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "p*", "**", "*counter_collection.csv"), recursive=True):
     rows = collections.defaultdict(list)              # (key, counter) -> [(dispatch id, value)]
