@@ -28,7 +28,7 @@ HIT_COLS = [COL.P, COL.P + 1, COL.P + 2, COL.N, COL.N + 1, COL.N + 2, COL.UV, CO
 def _report(name, payload):
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r05_wide_flips.json")
+    path = os.path.join(out_dir, "r06_wide_flips.json")
     try:
         j = json.load(open(path))
     except Exception:
@@ -391,6 +391,7 @@ def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""
     common_state = [None, 0, 0]                           # oracle state, cursor, iteration count at the last point both sides were identical
     explained = []
     ray_counts = {}                                       # iteration -> the oracle's raygen-queue length of the main run (what both pixel cursors were advanced by)
+    replay2 = [0, 0]                                      # times the oracle had to follow the device (explain_forks, step 2) | paths it reproduced that way
     shifted_total, last_shifted = [0], [0]                # paths whose pixel moved behind a tie that changed its path's termination (explain_forks)
 
     def explain_forks(bad_paths, upto, what, sg_main, so_main):
@@ -462,6 +463,7 @@ def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""
                     print(f"[fork] path {x}: device main run vs oracle following the device's ties differ in " + ", ".join(f"{common.colname(c)}: {sg_main[c][x]!r} vs {so2[c][x]!r}" for c in cols))
             assert not still.any(), (f"{workload} {what}: {int(still.sum())} paths of the device's main run are NOT what the oracle computes from the device's own tie choices "
                                      f"(first: {np.nonzero(still)[0][:8]}; ties: {sorted(tied)[:8]}, in replay 2: {sorted(tied2)[:8]})")
+            replay2[0] += 1; replay2[1] += len(rest)
             shifted = rest - tied2                        # regenerated onto the neighbouring pixel behind a tie (or forked by a tie of their own on that new path: tied2)
             tied |= (tied2 & rest)
             for c in (g, o):                              # back to where the main loop continues: the oracle's own run
@@ -518,7 +520,9 @@ def _bench_launch_chain_vs_oracle(workload, n, iters, start_iterations=0, tag=""
             assert common.fb_close(pg, po), f"{workload}: framebuffers differ"
     _report(f"bench_chain_vs_oracle_{tag}{workload}", {"paths": n, "iterations": iters, "rays": rays, "extension_rays": ext_rays,
                                                   "paths_forked_by_a_tie": forked, "forks_shown_to_be_ties_by_replay": len(explained),
-                                                  "paths_regenerated_onto_the_neighbouring_pixel_behind_such_a_tie": shifted_total[0]})
+                                                  "paths_regenerated_onto_the_neighbouring_pixel_behind_such_a_tie": shifted_total[0],
+                                                  "stretches_replayed_with_the_oracle_following_the_device": replay2[0],
+                                                  "paths_the_oracle_reproduced_bit_for_bit_from_the_device_tie_choices": replay2[1]})
     g.close()
 
 
