@@ -271,7 +271,16 @@ def test_opencl_runtime_loads_the_reference_code_objects():
         for flavour in ("ieee", "fast"):
             prog = B.load(os.path.join(rg.co_dir(flavour), file + ".co"))
             assert B.kernel(prog, entry)
-    _report("device", {"opencl_device": B.device_name(), "code_objects": len(names) * 2})
+    # ... and the 16 USE_ENV_MAP variants of `logic` built with the image stand-in (module docstring), through both loaders
+    H = rg.backend("hip")
+    env_ids = (2, 3, 6, 7, 10, 11, 14, 15, 18, 19, 22, 23, 26, 27, 30, 31)
+    for v in env_ids:
+        for flavour in ("ieee", "fast"):
+            path = os.path.join(rg.co_dir(flavour), f"logic_v{v}_imgstandin.co")
+            assert os.path.exists(path), path
+            assert H.kernel(H.load(path), "logic")
+            assert B.kernel(B.load(path), "logic")
+    _report("device", {"opencl_device": B.device_name(), "code_objects": len(names) * 2, "image_standin_code_objects": len(env_ids) * 2})
 
 
 @pytest.mark.parametrize("area,env,expl,impl,sep,roulette", [
